@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py - IK solutions/sec of the MI355X engine on BASELINE.json's headline configuration.
+
+  python bench.py --gpus 1 --steps 50 --warmup 10
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path (IKFlowSolver.generate_ik_solutions: 12-block conditional-flow inverse pass, slice,
+clamp) over one batch of B=4096 synthetic target poses per GPU, inputs resident in HBM.  Weights are seeded random
+(nn.Linear default init) of the released architecture `panda__full__lp191_5.25m` - the released weight file is a
+remote URL and there is no network.  With N > 1 every rank processes its own 4096-row shard (weak scaling) and the
+step ends with the one RCCL all-gather of the [4096 x 7] solutions.
+
+Rank 0 prints ONE JSON line: metric/value/unit per BASELINE.json, plus `roofline` for the dominant kernel
+(k_gemm_lrelu: the [B x 1024].[1024 x 1024]^T fp32-MFMA contraction) and `cpu_baseline` (the torch-CPU oracle timed on
+this host's cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+MODEL = "panda__full__lp191_5.25m"
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--batch", type=int, default=4096, help="target poses per GPU per step")
+    p.add_argument("--model", type=str, default=MODEL)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
+    p.add_argument("--gemm-variant", type=int, default=-1)
+    p.add_argument("--extras", action="store_true", help="also time B=512 approx and exact IK (reported under `extra`)")
+    return p.parse_args()
+
+
+def cpu_baseline(sd, layout, limits, poses_cpu, latent_cpu, budget_s):
+    """The oracle (op-for-op the reference's PyTorch-CPU path) on this host, same batch, bounded wall time."""
+    from oracle import flow_oracle as fo
+
+    threads = torch.get_num_threads()
+    n = poses_cpu.shape[0]
+    t0 = time.perf_counter()
+    fo.generate_ik_solutions_torch(sd, layout, limits, poses_cpu, latent_cpu)  # warm-up pass
+    t_warm = time.perf_counter() - t0
+    reps = max(1, min(50, int(budget_s / max(t_warm, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fo.generate_ik_solutions_torch(sd, layout, limits, poses_cpu, latent_cpu)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n * reps / dt,
+        "unit": "IK solutions/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{reps} passes of the same B={n} batch through oracle/flow_oracle.py (torch-CPU fp32, {threads} threads), {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the engine has no CPU path)"
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from ikflow_amd.ikflow_solver import IKFlowSolver
+    from ikflow_amd.model import hparams_for, layout_from, random_state_dict
+    from ikflow_amd.robots import get_robot
+    from ikflow_amd.model import MODEL_DESCRIPTIONS
+
+    robot = get_robot(MODEL_DESCRIPTIONS[args.model]["robot_name"])
+    hp = hparams_for(args.model)
+    layout = layout_from(hp, robot)
+    sd = random_state_dict(layout, robot, seed=0)
+    solver = IKFlowSolver(hp, robot)
+    solver.load_state_dict_tensors(sd)
+    eng = solver.engine(dev)
+    if args.gemm_variant >= 0:
+        eng.set_gemm_variant(args.gemm_variant)
+
+    B = args.batch
+    # poses = FK(q), q ~ U(lo+eps, hi-eps), numpy default_rng(seed); latents N(0,1)
+    q = torch.tensor(robot.sample_joint_angles(B, 0.004363323129985824, np.random.default_rng(rank)), device=dev)
+    poses = robot.forward_kinematics(q)
+    latent = torch.randn(B, layout.dim, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    eng.reserve(B)
+    gathered = torch.empty((world * B, layout.ndof), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        sol = solver.generate_ik_solutions(poses, latent=latent)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, sol)
+        return sol
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sol = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(sol).all())
+
+    # dominant kernel: HIP-event timing of back-to-back launches on the engine's stream, same shapes/data as above
+    gemm_ms = eng.time_gemm(B, 200)
+    flop_per_launch = 2.0 * B * layout.width * layout.width
+    achieved = flop_per_launch / (gemm_ms * 1e-3) / 1e12
+    value = world * B * args.steps / elapsed
+    flow_tflops = value / world * layout.flops_per_solution() / 1e12
+
+    extra = {"flow_tflops_per_gpu": round(flow_tflops, 2), "gemm_ms": round(gemm_ms, 5),
+             "gemm_launches_per_step": 2 * layout.nb_nodes * (layout.n_hidden - 1)}
+    if args.extras and rank == 0:
+        extra.update(run_extras(solver, eng, robot, layout, dev))
+
+    out = {
+        "metric": "IK solutions/sec (approx), Panda 12-node flow, batch 4096 per GPU",
+        "value": value,
+        "unit": "IK solutions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1000.0 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (seeded random weights of the released architecture; poses = FK(uniform q); N(0,1) latents)",
+        "config": {"workload": f"{args.model} generate_ik_solutions, B={B} poses per GPU per step, clamp_to_joint_limits",
+                   "global_batch": world * B, "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": eng.dominant_kernel_name(),
+                     "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms},
+        "extra": extra,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd, layout, robot.actuated_joints_limits, poses.cpu(), latent.cpu(), args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_extras(solver, eng, robot, layout, dev):
+    """Secondary numbers (not the headline): B=512 approx and exact IK at B=4096."""
+    res = {}
+    for b in (512,):
+        q = torch.tensor(robot.sample_joint_angles(b, 0.004363323129985824, np.random.default_rng(5)), device=dev)
+        poses = robot.forward_kinematics(q)
+        lat = torch.randn(b, layout.dim, device=dev)
+        for _ in range(5):
+            solver.generate_ik_solutions(poses, latent=lat)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        k = 50
+        for _ in range(k):
+            solver.generate_ik_solutions(poses, latent=lat)
+        torch.cuda.synchronize(dev)
+        res[f"approx_B{b}_solutions_per_s"] = b * k / (time.perf_counter() - t0)
+    b = 4096
+    q = torch.tensor(robot.sample_joint_angles(b, 0.004363323129985824, np.random.default_rng(6)), device=dev)
+    poses = robot.forward_kinematics(q)
+    for _ in range(2):
+        solver.generate_exact_ik_solutions(poses, pos_error_threshold=1e-3, rot_error_threshold=0.01)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    k = 5
+    nvalid = 0
+    for _ in range(k):
+        _, valid = solver.generate_exact_ik_solutions(poses, pos_error_threshold=1e-3, rot_error_threshold=0.01)
+        nvalid += int(valid.sum().item())
+    dt = time.perf_counter() - t0
+    res["exact_B4096_target_poses_per_s"] = b * k / dt
+    res["exact_B4096_valid_per_s"] = nvalid / dt
+    res["exact_note"] = "random weights: flow seeds are uninformative, so valid/s measures arithmetic cost, not convergence"
+    return res
+
+
+if __name__ == "__main__":
+    main()

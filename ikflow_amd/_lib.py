@@ -1,0 +1,119 @@
+"""ctypes binding of libikflow_amd.so (the C-ABI declared in include/ikflow_amd.h).
+
+There is no fallback: if the in-tree shared library is missing or does not load, importing the binding raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from ikflow_amd import build as _build
+
+IKF_ABI_VERSION = 1
+IKF_MAX_DOF = 8
+IKF_MAX_DIM = 16
+IKF_MAX_ROUNDS = 8
+
+IKF_OK = 0
+IKF_ERR_NULL_POINTER = 1
+IKF_ERR_BAD_SHAPE = 2
+IKF_ERR_NOT_LOADED = 3
+IKF_ERR_MISSING_TENSOR = 4
+IKF_ERR_HIP = 5
+IKF_ERR_NO_DEVICE = 6
+IKF_ERR_BAD_ARGUMENT = 7
+
+
+class ikf_joint(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("axis", C.c_float * 3), ("pre", C.c_float * 12)]
+
+
+class ikf_model_desc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("nb_nodes", C.c_int32),
+        ("dim", C.c_int32),
+        ("dim_cond", C.c_int32),
+        ("width", C.c_int32),
+        ("n_hidden", C.c_int32),
+        ("clamp", C.c_float),
+        ("leaky_slope", C.c_float),
+        ("ndof", C.c_int32),
+        ("joint_lo", C.c_float * IKF_MAX_DOF),
+        ("joint_hi", C.c_float * IKF_MAX_DOF),
+        ("chain", ikf_joint * IKF_MAX_DOF),
+        ("tool", C.c_float * 12),
+    ]
+
+
+class ikf_tensor(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("h_data", C.c_void_p),
+        ("dtype", C.c_int32),
+        ("ndim", C.c_int32),
+        ("shape", C.c_int64 * 4),
+    ]
+
+
+LATENT_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int)
+
+# name -> (restype, argtypes); every symbol include/ikflow_amd.h declares
+SIGNATURES = {
+    "ikf_create": (C.c_int, [C.POINTER(ikf_model_desc), C.c_int, C.POINTER(C.c_void_p)]),
+    "ikf_destroy": (None, [C.c_void_p]),
+    "ikf_last_error": (C.c_char_p, []),
+    "ikf_abi_version": (C.c_int, []),
+    "ikf_load_weights": (C.c_int, [C.c_void_p, C.POINTER(ikf_tensor), C.c_int]),
+    "ikf_weights_loaded": (C.c_int, [C.c_void_p]),
+    "ikf_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ikf_generate_approx": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
+    ),
+    "ikf_forward_kinematics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ikf_pose_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ikf_lm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ikf_jacobian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ikf_clamp_to_joint_limits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ikf_joint_limits_exceeded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ikf_generate_exact": (
+        C.c_int,
+        [
+            C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float,
+            LATENT_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+        ],
+    ),
+    "ikf_time_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "ikf_dominant_kernel_name": (C.c_char_p, []),
+    "ikf_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+LIB_PATH = _build.LIB_PATH
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built (run `python -m ikflow_amd.build`). "
+            "ikflow_amd has no CPU path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.ikf_abi_version()
+    if got != IKF_ABI_VERSION:
+        raise ImportError(f"libikflow_amd.so ABI {got} != binding ABI {IKF_ABI_VERSION}; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ikf_last_error().decode("utf-8", "replace")

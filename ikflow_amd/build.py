@@ -1,0 +1,64 @@
+"""Builds libikflow_amd.so (HIP, gfx950 only) in-tree with hipcc.  `python -m ikflow_amd.build [--force]`."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from typing import List
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_DIR = os.path.join(_HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libikflow_amd.so")
+SOURCES = ["flow_kernels.hip", "kin_kernels.hip", "ikf_api.hip"]
+HEADERS = [os.path.join(CSRC, "ikf_internal.h"), os.path.join(_HERE, "..", "include", "ikflow_amd.h")]
+ARCH = "gfx950"
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libikflow_amd.so cannot be built (no prebuilt library in-tree either)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit for gfx950 and link the shared library. Returns its path."""
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    os.makedirs(LIB_DIR, exist_ok=True)
+    objs: List[str] = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
+        if verbose and out.strip():
+            print(out)
+    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + " ".join(link) + "\n" + r.stdout)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

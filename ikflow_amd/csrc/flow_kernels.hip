@@ -1,0 +1,421 @@
+// Conditional-flow inverse pass for gfx950 (MI355X): the three kernels one coupling subnet is made of.
+//
+// Replaces, per coupling block and subnet, what FrEIA's GLOWCouplingBlock.forward(rev=True) launches through torch
+// (call site ikflow/ikflow_solver.py:98; graph ikflow/model.py:300-354; subnet ikflow/model.py:51-96):
+//
+//   k_first_layer            cat[x_part, cond] -> Linear(in, W) -> LeakyReLU            (in = 10..15: VALU, HBM-write bound)
+//   k_gemm_lrelu             Linear(W, W) -> LeakyReLU as a [rows x W] . [W x W]^T contraction on the f32 MFMA
+//                            (v_mfma_f32_32x32x2_f32) - 99 % of the FLOPs, the dominant kernel
+//   k_last_layer_coupling    Linear(W, 2L) -> split s|t -> s = clamp*0.636*atan(s) -> y = (x - t)*exp(-s)
+//                            -> (subnet 2) cat + PermuteRandom^-1 gather -> (last block) FixedLinearTransform^-1,
+//                            [:, :ndof], clamp_to_joint_limits   (ikflow_solver.py:99-102)
+//
+// All arithmetic is fp32 (ikflow/config.py:8); the MFMA used is the exact-f32 one (bitwise an fmaf chain).
+#include "ikf_internal.h"
+
+namespace ikf {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// first Linear + LeakyReLU
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FIRST_ROWS_PER_BLOCK = 16;
+
+template <int IN>
+__global__ __launch_bounds__(256) void k_first_layer(const float* __restrict__ w_t, const float* __restrict__ w_soft,
+                                                     const float* __restrict__ bias, const float* __restrict__ x_in,
+                                                     int D, int x_off, int n_x, PoseSource ps, long long row0,
+                                                     long long rows, int width, float slope,
+                                                     float* __restrict__ h_out) {
+  const long long r_begin = (long long)blockIdx.x * FIRST_ROWS_PER_BLOCK;
+  const long long r_end = (r_begin + FIRST_ROWS_PER_BLOCK < rows) ? r_begin + FIRST_ROWS_PER_BLOCK : rows;
+  const int n4 = width >> 2;
+  for (int c4 = threadIdx.x; c4 < n4; c4 += blockDim.x) {
+    float4 w[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) w[k] = reinterpret_cast<const float4*>(w_t + (size_t)k * width)[c4];
+    float4 b = reinterpret_cast<const float4*>(bias)[c4];
+    if (ps.softflow != 0.0f) {
+      const float4 ws = reinterpret_cast<const float4*>(w_soft)[c4];
+      b.x = fmaf(ps.softflow, ws.x, b.x);
+      b.y = fmaf(ps.softflow, ws.y, b.y);
+      b.z = fmaf(ps.softflow, ws.z, b.z);
+      b.w = fmaf(ps.softflow, ws.w, b.w);
+    }
+    for (long long r = r_begin; r < r_end; ++r) {
+      // block-uniform addresses: the compiler turns these into scalar loads
+      const long long gr = row0 + r;
+      const long long pm = gr % ps.n_mod;
+      const long long pi = ps.idx ? (long long)ps.idx[pm] : pm;
+      const float* pose = ps.poses + pi * ps.stride;
+      const float* xr = x_in + (size_t)r * D + x_off;
+      float4 acc = b;
+#pragma unroll
+      for (int k = 0; k < IN; ++k) {
+        const float u = (k < n_x) ? xr[k < n_x ? k : 0] : pose[k - n_x];
+        acc.x = fmaf(u, w[k].x, acc.x);
+        acc.y = fmaf(u, w[k].y, acc.y);
+        acc.z = fmaf(u, w[k].z, acc.z);
+        acc.w = fmaf(u, w[k].w, acc.w);
+      }
+      acc.x = acc.x > 0.f ? acc.x : acc.x * slope;
+      acc.y = acc.y > 0.f ? acc.y : acc.y * slope;
+      acc.z = acc.z > 0.f ? acc.z : acc.z * slope;
+      acc.w = acc.w > 0.f ? acc.w : acc.w * slope;
+      reinterpret_cast<float4*>(h_out + (size_t)r * width)[c4] = acc;
+    }
+  }
+}
+
+hipError_t launch_first_layer(const SubnetWeights& w, const FlowDims& d, const float* x_in, int x_off,
+                              const PoseSource& ps, long long row0, long long rows, float* h_out, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  const int in_real = w.n_x + d.n_pose;
+  const unsigned grid = (unsigned)((rows + FIRST_ROWS_PER_BLOCK - 1) / FIRST_ROWS_PER_BLOCK);
+  const int threads = (d.width / 4 >= 256) ? 256 : ((d.width / 4 + 63) / 64) * 64;
+#define IKF_FIRST_CASE(IN)                                                                                       \
+  case IN:                                                                                                       \
+    hipLaunchKernelGGL((k_first_layer<IN>), dim3(grid), dim3(threads), 0, s, w.w_first_t, w.w_soft, w.b_first,    \
+                       x_in, d.D, x_off, w.n_x, ps, row0, rows, d.width, d.slope, h_out);                         \
+    break;
+  switch (in_real) {
+    IKF_FIRST_CASE(8)
+    IKF_FIRST_CASE(9)
+    IKF_FIRST_CASE(10)
+    IKF_FIRST_CASE(11)
+    IKF_FIRST_CASE(12)
+    IKF_FIRST_CASE(13)
+    IKF_FIRST_CASE(14)
+    IKF_FIRST_CASE(15)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef IKF_FIRST_CASE
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hidden Linear + LeakyReLU:  C[m][n] = lrelu( sum_k A[m][k] * W[n][k] + bias[n] )
+//
+// Both operands are K-contiguous, so A and W tiles are staged identically: global float4 -> ds_write_b128 into a
+// [rows][BK+4] LDS image (the +4 pad makes the ds_read_b128 fragment reads conflict-free: row stride 36 dwords),
+// double buffered, one barrier per K tile.  Fragments: lane l reads 4 consecutive k of row (l&31) at k-offset
+// 4*(l>>5); component c of that float4 feeds MFMA c, i.e. MFMA c contracts k = {k0+c, k0+4+c} - a permutation of
+// the k order that A and W share, so the contraction is unchanged.
+// C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_gemm_lrelu(const float* __restrict__ A,
+                                                                       const float* __restrict__ W,
+                                                                       const float* __restrict__ bias,
+                                                                       float* __restrict__ C, int M, int N, int K,
+                                                                       float slope) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int LDK = BK + 4;
+  constexpr int KQ = BK / 4;                 // float4 per tile row
+  constexpr int A_F4 = BM * KQ / NT;         // float4 per thread for the A tile
+  constexpr int B_F4 = BN * KQ / NT;
+  static_assert(BM * KQ % NT == 0 && BN * KQ % NT == 0, "tile/threads mismatch");
+  static_assert(BK % 8 == 0, "BK must be a multiple of 8");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                          // [2][BM][LDK]
+  float* sB = smem + 2 * BM * LDK;           // [2][BN][LDK]
+
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of logical tiles
+  // (consecutive tiles share the A row panel) - speed only, any mapping is correct.
+  const int tiles_n = N / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // global staging: thread t owns float4 (row_t + i*RS, kq_t) of each tile, i = 0..F4-1
+  constexpr int RS = NT / KQ;  // tile rows covered by one pass of the workgroup
+  static_assert(NT % KQ == 0, "threads must cover whole tile rows");
+  const int row_t = t / KQ, kq_t = (t % KQ) * 4;
+  floatx4 ra[A_F4], rb[B_F4];
+  const float* a_base = A + kq_t;
+  const float* b_base = W + (size_t)(n0 + row_t) * K + kq_t;
+  const int lds_t = row_t * LDK + kq_t;
+
+  const int KT = K / BK;
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    int gr = m0 + row_t + i * RS;
+    gr = gr < M ? gr : M - 1;  // rows past M are computed on a clamped row and never stored
+    ra[i] = *reinterpret_cast<const floatx4*>(a_base + (size_t)gr * K);
+  }
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K);
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sA + lds_t + i * RS * LDK) = ra[i];
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) *reinterpret_cast<floatx4*>(sB + lds_t + i * RS * LDK) = rb[i];
+  __syncthreads();
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (kt + 1 < KT);
+    if (more) {
+      const int koff = (kt + 1) * BK;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) {
+        int gr = m0 + row_t + i * RS;
+        gr = gr < M ? gr : M - 1;
+        ra[i] = *reinterpret_cast<const floatx4*>(a_base + (size_t)gr * K + koff);
+      }
+#pragma unroll
+      for (int i = 0; i < B_F4; ++i) rb[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + koff);
+    }
+    const float* cA = sA + cur * BM * LDK + (wm + frag_row) * LDK + frag_k;
+    const float* cB = sB + cur * BN * LDK + (wn + frag_row) * LDK + frag_k;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      floatx4 fa[MI], fb[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *reinterpret_cast<const floatx4*>(cA + i * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) fb[j] = *reinterpret_cast<const floatx4*>(cB + j * 32 * LDK + kk * 8);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) {
+      float* nA = sA + (cur ^ 1) * BM * LDK;
+      float* nB = sB + (cur ^ 1) * BN * LDK;
+#pragma unroll
+      for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(nA + lds_t + i * RS * LDK) = ra[i];
+#pragma unroll
+      for (int i = 0; i < B_F4; ++i) *reinterpret_cast<floatx4*>(nB + lds_t + i * RS * LDK) = rb[i];
+    }
+    __syncthreads();
+  }
+
+  // epilogue: bias + LeakyReLU, direct stores (each half-wave writes 128 contiguous bytes per register)
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn + j * 32 + col_l;
+    const float bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        float v = acc[i][j][r] + bv;
+        v = v > 0.f ? v : v * slope;
+        if (row < M) C[(size_t)row * N + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static hipError_t launch_gemm_t(const float* A, const float* W, const float* bias, float* C, long long M, int N, int K,
+                                float slope, hipStream_t s) {
+  if (N % BN != 0 || K % BK != 0) return hipErrorInvalidValue;
+  constexpr int LDK = BK + 4;
+  constexpr size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+  auto kern = k_gemm_lrelu<BM, BN, BK, WAVES_M, WAVES_N>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long long tiles_m = (M + BM - 1) / BM;
+  const long long grid = tiles_m * (N / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), smem, s, A, W, bias, C, (int)M, N, K,
+                     slope);
+  return hipGetLastError();
+}
+
+int gemm_variant_count() { return 6; }
+const char* gemm_kernel_name() { return "k_gemm_lrelu"; }
+
+hipError_t launch_gemm_lrelu(int variant, const float* A, const float* W, const float* bias, float* C, long long M,
+                             int N, int K, float slope, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  switch (variant) {
+    case 0:  // 128x128 tile, 4 waves of 64x64, BK 32: 256 tiles at M=4096,N=1024 = one per CU
+      return launch_gemm_t<128, 128, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    case 1:  // 128x128, 8 waves of 64x32
+      return launch_gemm_t<128, 128, 32, 2, 4>(A, W, bias, C, M, N, K, slope, s);
+    case 2:  // 128x64, 4 waves of 64x32: 512 tiles, two de-phased workgroups per CU
+      return launch_gemm_t<128, 64, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    case 3:  // 128x128, BK 64
+      return launch_gemm_t<128, 128, 64, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    case 4:  // 64x64 tile, 4 waves of 32x32: small batches (M=512 -> 128 tiles)
+      return launch_gemm_t<64, 64, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    case 5:  // 64x128
+      return launch_gemm_t<64, 128, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    default:
+      return hipErrorInvalidValue;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// last Linear + affine-coupling inverse (+ permutation, + final rescale/clamp)
+// one wave per row; lane l owns k = 4*(64*g + l) .. +3 of the hidden row; the OUT x width weights live in VGPRs
+// ---------------------------------------------------------------------------------------------------------------
+template <int OUT, int G>
+__global__ __launch_bounds__(256) void k_last_layer_coupling(const float* __restrict__ w_last,
+                                                             const float* __restrict__ b_last,
+                                                             const float* __restrict__ h, FlowDims d, CouplingArgs ca,
+                                                             long long rows) {
+  const int lane = threadIdx.x & 63;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int width = d.width;
+
+  float4 w[OUT][G];
+#pragma unroll
+  for (int j = 0; j < OUT; ++j)
+#pragma unroll
+    for (int g = 0; g < G; ++g) w[j][g] = reinterpret_cast<const float4*>(w_last + (size_t)j * width)[g * 64 + lane];
+
+  const int D = d.D, L1 = d.L1, L2 = d.L2;
+  const int nl = (ca.which == 1) ? L2 : L1;  // number of (s,t) pairs this subnet emits
+
+  for (long long row = wave0; row < rows; row += nwaves) {
+    float4 hv[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) hv[g] = reinterpret_cast<const float4*>(h + (size_t)row * width)[g * 64 + lane];
+    float a[OUT];
+#pragma unroll
+    for (int j = 0; j < OUT; ++j) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        sacc = fmaf(hv[g].x, w[j][g].x, sacc);
+        sacc = fmaf(hv[g].y, w[j][g].y, sacc);
+        sacc = fmaf(hv[g].z, w[j][g].z, sacc);
+        sacc = fmaf(hv[g].w, w[j][g].w, sacc);
+      }
+      a[j] = sacc;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+      for (int j = 0; j < OUT; ++j) a[j] += __shfl_xor(a[j], off, 64);
+
+    // lane j < nl takes (s_j, t_j) = (a[j], a[nl + j]) + bias
+    float sv = 0.f, tv = 0.f;
+#pragma unroll
+    for (int j = 0; j < OUT; ++j) {
+      const float aj = a[j] + b_last[j];
+      if (j == lane) sv = aj;
+      if (j == lane + nl) tv = aj;
+    }
+    // FrEIA: s = clamp * (0.636 * atan(s));  y = (x - t) * exp(-s)
+    const float s_cl = d.clamp * (0.636f * atanf(sv));
+    const float e = expf(-s_cl);
+
+    if (ca.which == 1) {
+      float xv = 0.f;
+      if (lane < D) xv = ca.x_in[(size_t)row * D + lane];
+      // lanes L1..D-1 hold x2; the (s,t) for x2[j] sit in lane j -> fetch from lane (lane - L1)
+      const int src = (lane >= L1 && lane < D) ? lane - L1 : 0;
+      const float t_j = __shfl(tv, src, 64);
+      const float e_j = __shfl(e, src, 64);
+      float outv = xv;  // x1 is carried through unchanged
+      if (lane >= L1 && lane < D) outv = (xv - t_j) * e_j;
+      if (lane < D) ca.x_out[(size_t)row * D + lane] = outv;
+    } else {
+      // state row = [x1 | y2]; y1 = (x1 - t2) * exp(-s2) on lanes < L1
+      float xv = 0.f;
+      if (lane < D) xv = ca.x_out[(size_t)row * D + lane];
+      float cat = xv;
+      if (lane < L1) cat = (xv - tv) * e;
+      // PermuteRandom rev: out[:, d] = cat[:, perm_inv[d]]
+      const int src = (lane < D) ? ca.perm_inv[lane] : 0;
+      const float v = __shfl(cat, src, 64);
+      if (!ca.is_final) {
+        if (lane < D) ca.x_out[(size_t)row * D + lane] = v;
+      } else {
+        // FixedLinearTransform rev: (x - b).mm(M_inv); then [:, :ndof] and clamp_to_joint_limits
+        const float xm = (lane < D) ? v - ca.b_lin[lane] : 0.f;
+        float q = 0.f;
+        const int jcol = lane < D ? lane : 0;
+        for (int k = 0; k < D; ++k) q = fmaf(__shfl(xm, k, 64), ca.M_inv[k * D + jcol], q);
+        if (lane < d.ndof) {
+          if (ca.clamp_limits) q = fminf(fmaxf(q, ca.lo[lane]), ca.hi[lane]);
+          ca.q_out[(size_t)row * d.ndof + lane] = q;
+        }
+      }
+    }
+  }
+}
+
+template <int OUT>
+static hipError_t launch_last_g(const SubnetWeights& w, const FlowDims& d, const float* h_in, const CouplingArgs& ca,
+                                long long rows, hipStream_t s) {
+  const int G = d.width / 256;
+  long long waves = (rows + 3) / 4;  // ~4 rows per wave amortises the weight-register fill
+  if (waves < 1) waves = 1;
+  const unsigned grid = (unsigned)((waves + 3) / 4);
+#define IKF_LAST_CASE(GG)                                                                                        \
+  case GG:                                                                                                       \
+    hipLaunchKernelGGL((k_last_layer_coupling<OUT, GG>), dim3(grid), dim3(256), 0, s, w.w_last, w.b_last, h_in, d, \
+                       ca, rows);                                                                                \
+    break;
+  switch (G) {
+    IKF_LAST_CASE(1)
+    IKF_LAST_CASE(2)
+    IKF_LAST_CASE(4)
+    default:
+      return hipErrorInvalidValue;
+  }
+#undef IKF_LAST_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_last_layer_coupling(const SubnetWeights& w, const FlowDims& d, const float* h_in,
+                                      const CouplingArgs& ca, long long rows, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (d.width % 256 != 0) return hipErrorInvalidValue;
+  switch (w.n_out) {
+    case 4: return launch_last_g<4>(w, d, h_in, ca, rows, s);
+    case 6: return launch_last_g<6>(w, d, h_in, ca, rows, s);
+    case 8: return launch_last_g<8>(w, d, h_in, ca, rows, s);
+    case 10: return launch_last_g<10>(w, d, h_in, ca, rows, s);
+    case 12: return launch_last_g<12>(w, d, h_in, ca, rows, s);
+    case 14: return launch_last_g<14>(w, d, h_in, ca, rows, s);
+    case 16: return launch_last_g<16>(w, d, h_in, ca, rows, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ikf

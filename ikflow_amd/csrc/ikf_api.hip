@@ -1,0 +1,586 @@
+// C-ABI of libikflow_amd.so: handle lifetime, weight packing, and the host-side orchestration of the approximate and
+// exact IK paths (the launches that replace IKFlowSolver._run_inference / _generate_exact_ik_solutions,
+// ikflow/ikflow_solver.py:85-247, 345-411).  See include/ikflow_amd.h for the contract.
+#include <cstddef>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ikf_internal.h"
+
+using namespace ikf;
+
+static thread_local std::string g_last_error;
+
+static ikf_status fail(ikf_status code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+#define IKF_HIP(call)                                                                                          \
+  do {                                                                                                         \
+    hipError_t e_ = (call);                                                                                    \
+    if (e_ != hipSuccess)                                                                                      \
+      return fail(IKF_ERR_HIP, std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + \
+                                   std::to_string(__LINE__) + ")");                                            \
+  } while (0)
+
+struct ikf_model {
+  int device = 0;
+  ikf_model_desc desc{};
+  FlowDims dims{};
+  bool loaded = false;
+  int gemm_variant = -1;  // -1 = choose by batch size
+
+  // packed weights (one arena)
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  std::vector<SubnetWeights> subnets;  // [2*block + (which-1)]
+  int* d_perm_inv = nullptr;           // [nb_nodes][D]
+  float* d_Minv = nullptr;             // [D][D]
+  float* d_blin = nullptr;             // [D]
+  Chain* d_chain = nullptr;            // robot chain + limits
+
+  // scratch
+  long long chunk_rows = 0;  // capacity of the per-chunk flow scratch
+  float* xbuf = nullptr;     // [chunk][D]
+  float* hA = nullptr;       // [chunk][width]
+  float* hB = nullptr;
+  // exact-IK scratch
+  long long exact_rows = 0, exact_poses = 0;
+  float* ex_q = nullptr;          // [rows][ndof]
+  uint8_t* ex_row_valid = nullptr;  // [rows]
+  int* ex_pose_idx = nullptr;     // [poses]
+  uint8_t* ex_solved = nullptr;   // [poses]
+  int* ex_count = nullptr;        // device
+  int* h_count = nullptr;         // pinned host
+};
+
+static const long long kMaxChunkRows = 16384;  // keeps the [chunk x width] activations (64 MB each) inside the 256 MB L3
+
+extern "C" const char* ikf_last_error(void) { return g_last_error.c_str(); }
+extern "C" int ikf_abi_version(void) { return IKF_ABI_VERSION; }
+extern "C" const char* ikf_dominant_kernel_name(void) { return gemm_kernel_name(); }
+
+static void free_scratch(ikf_model* m) {
+  if (m->xbuf) (void)hipFree(m->xbuf);
+  if (m->hA) (void)hipFree(m->hA);
+  if (m->hB) (void)hipFree(m->hB);
+  m->xbuf = m->hA = m->hB = nullptr;
+  m->chunk_rows = 0;
+}
+static void free_exact(ikf_model* m) {
+  if (m->ex_q) (void)hipFree(m->ex_q);
+  if (m->ex_row_valid) (void)hipFree(m->ex_row_valid);
+  if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
+  if (m->ex_solved) (void)hipFree(m->ex_solved);
+  m->ex_q = nullptr; m->ex_row_valid = nullptr; m->ex_pose_idx = nullptr; m->ex_solved = nullptr;
+  m->exact_rows = m->exact_poses = 0;
+}
+
+extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_model** out) {
+  if (!desc || !out) return fail(IKF_ERR_NULL_POINTER, "ikf_create: null argument");
+  *out = nullptr;
+  if (desc->abi_version != IKF_ABI_VERSION)
+    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_create: ABI version mismatch (header " + std::to_string(IKF_ABI_VERSION) +
+                                          ", caller " + std::to_string(desc->abi_version) + ")");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(IKF_ERR_NO_DEVICE, "ikf_create: no HIP device visible (this engine has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_create: device index out of range");
+  const int D = desc->dim;
+  if (desc->nb_nodes < 1 || D < 2 || D > IKF_MAX_DIM) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: nb_nodes/dim out of range (2 <= D <= 16)");
+  if (desc->dim_cond != 7 && desc->dim_cond != 8) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: dim_cond must be 7 or 8");
+  if (desc->n_hidden < 1 || desc->n_hidden > 4) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: Number of layers `n_layers` must be in [1, ..., 4]");
+  if (desc->width < 256 || desc->width % 256 != 0 || desc->width > 1024)
+    return fail(IKF_ERR_BAD_SHAPE, "ikf_create: coeff_fn_internal_size must be 256, 512, 768 or 1024 for the gfx950 kernels");
+  if (desc->ndof < 4 || desc->ndof > IKF_MAX_DOF || desc->ndof > D)
+    return fail(IKF_ERR_BAD_SHAPE, "ikf_create: ndof must be in [4, 8] and <= dim");
+  IKF_HIP(hipSetDevice(device));
+
+  ikf_model* m = new ikf_model();
+  m->device = device;
+  m->desc = *desc;
+  m->dims.D = D;
+  m->dims.L1 = D / 2;  // ikflow/model.py:336 (old FrEIA rule)
+  m->dims.L2 = D - D / 2;
+  m->dims.width = desc->width;
+  m->dims.n_hidden = desc->n_hidden;
+  m->dims.ndof = desc->ndof;
+  m->dims.n_pose = 7;
+  m->dims.clamp = desc->clamp;
+  m->dims.slope = desc->leaky_slope;
+
+  Chain ch{};
+  ch.ndof = desc->ndof;
+  for (int j = 0; j < desc->ndof; ++j) {
+    ch.joints[j] = desc->chain[j];
+    ch.lo[j] = desc->joint_lo[j];
+    ch.hi[j] = desc->joint_hi[j];
+    if (ch.joints[j].kind != 1 && ch.joints[j].kind != 2) {
+      delete m;
+      return fail(IKF_ERR_BAD_ARGUMENT, "ikf_create: chain joint kind must be 1 (revolute) or 2 (prismatic)");
+    }
+  }
+  memcpy(ch.tool, desc->tool, sizeof(ch.tool));
+  hipError_t e = hipMalloc(&m->d_chain, sizeof(Chain));
+  if (e == hipSuccess) e = hipMemcpy(m->d_chain, &ch, sizeof(Chain), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&m->ex_count, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&m->h_count, sizeof(int));
+  if (e != hipSuccess) {
+    ikf_destroy(m);
+    return fail(IKF_ERR_HIP, std::string("ikf_create: allocation failed: ") + hipGetErrorString(e));
+  }
+  *out = m;
+  return IKF_OK;
+}
+
+extern "C" void ikf_destroy(ikf_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  free_scratch(m);
+  free_exact(m);
+  if (m->arena) (void)hipFree(m->arena);
+  if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
+  if (m->d_Minv) (void)hipFree(m->d_Minv);
+  if (m->d_blin) (void)hipFree(m->d_blin);
+  if (m->d_chain) (void)hipFree(m->d_chain);
+  if (m->ex_count) (void)hipFree(m->ex_count);
+  if (m->h_count) (void)hipHostFree(m->h_count);
+  delete m;
+}
+
+extern "C" int ikf_weights_loaded(const ikf_model* m) { return (m && m->loaded) ? 1 : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------------------------
+static const ikf_tensor* find_tensor(const std::unordered_map<std::string, const ikf_tensor*>& idx, const std::string& k) {
+  auto it = idx.find(k);
+  return it == idx.end() ? nullptr : it->second;
+}
+
+static ikf_status need(const std::unordered_map<std::string, const ikf_tensor*>& idx, const std::string& key, int dtype,
+                       std::initializer_list<int64_t> shape, const ikf_tensor** out) {
+  const ikf_tensor* t = find_tensor(idx, key);
+  if (!t) return fail(IKF_ERR_MISSING_TENSOR, "Missing key(s) in state_dict: \"" + key + "\"");
+  if (!t->h_data) return fail(IKF_ERR_NULL_POINTER, "state_dict tensor \"" + key + "\" has a null data pointer");
+  if (t->dtype != dtype) return fail(IKF_ERR_MISSING_TENSOR, "state_dict tensor \"" + key + "\" has the wrong dtype");
+  bool ok = (t->ndim == (int)shape.size());
+  int i = 0;
+  if (ok)
+    for (int64_t s : shape) ok = ok && (t->shape[i++] == s);
+  if (!ok) {
+    std::string got = "(", want = "(";
+    for (int k = 0; k < t->ndim; ++k) got += std::to_string(t->shape[k]) + (k + 1 < t->ndim ? ", " : "");
+    i = 0;
+    for (int64_t s : shape) want += std::to_string(s) + (++i < (int)shape.size() ? ", " : "");
+    return fail(IKF_ERR_MISSING_TENSOR, "size mismatch for " + key + ": copying a param with shape " + got +
+                                            ") from checkpoint, the shape in current model is " + want + ").");
+  }
+  *out = t;
+  return IKF_OK;
+}
+
+static size_t align64(size_t n) { return (n + 63) & ~size_t(63); }  // 64 floats = 256 B
+
+extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors) {
+  if (!m || !tensors) return fail(IKF_ERR_NULL_POINTER, "ikf_load_weights: null argument");
+  IKF_HIP(hipSetDevice(m->device));
+  std::unordered_map<std::string, const ikf_tensor*> idx;
+  for (int i = 0; i < n_tensors; ++i)
+    if (tensors[i].name) idx[tensors[i].name] = &tensors[i];
+
+  const FlowDims& d = m->dims;
+  const int D = d.D, W = d.width, NB = m->desc.nb_nodes, C = m->desc.dim_cond;
+  const int n_lin = d.n_hidden + 1;
+
+  // pass 1: sizes
+  size_t total = 0;
+  for (int b = 0; b < NB; ++b)
+    for (int which = 1; which <= 2; ++which) {
+      const int n_x = (which == 1) ? d.L1 : d.L2;
+      const int n_out = 2 * ((which == 1) ? d.L2 : d.L1);
+      total += align64((size_t)(n_x + 7) * W) + 2 * align64(W);           // first (transposed), soft column, bias
+      total += (size_t)(d.n_hidden - 1) * (align64((size_t)W * W) + align64(W));
+      total += align64((size_t)n_out * W) + align64(n_out);
+    }
+  std::vector<float> host(total, 0.f);
+  std::vector<SubnetWeights> subs(2 * NB);
+  std::vector<size_t> off_first(2 * NB), off_soft(2 * NB), off_bfirst(2 * NB), off_last(2 * NB), off_blast(2 * NB);
+  std::vector<std::vector<size_t>> off_mid(2 * NB), off_bmid(2 * NB);
+  std::vector<int> perm_host((size_t)NB * D);
+
+  size_t cur = 0;
+  for (int b = 0; b < NB; ++b) {
+    const std::string pkey = "module_list." + std::to_string(2 * b + 1) + ".perm_inv";
+    const ikf_tensor* tp = nullptr;
+    ikf_status st = need(idx, pkey, 1, {D}, &tp);
+    if (st != IKF_OK) return st;
+    std::vector<char> seen(D, 0);
+    for (int k = 0; k < D; ++k) {
+      const int64_t v = static_cast<const int64_t*>(tp->h_data)[k];
+      if (v < 0 || v >= D || seen[v]) return fail(IKF_ERR_MISSING_TENSOR, pkey + " is not a permutation of range(D)");
+      seen[v] = 1;
+      perm_host[(size_t)b * D + k] = (int)v;
+    }
+    for (int which = 1; which <= 2; ++which) {
+      const int si = 2 * b + which - 1;
+      const int n_x = (which == 1) ? d.L1 : d.L2;
+      const int n_out = 2 * ((which == 1) ? d.L2 : d.L1);
+      const std::string base = "module_list." + std::to_string(2 * b + 2) + ".subnet" + std::to_string(which) + ".";
+      // first Linear: weight [W][n_x + C] -> transposed [n_x + 7][W] (+ softflow column apart)
+      const ikf_tensor *tw = nullptr, *tb = nullptr;
+      st = need(idx, base + "0.weight", 0, {W, n_x + C}, &tw);
+      if (st != IKF_OK) return st;
+      st = need(idx, base + "0.bias", 0, {W}, &tb);
+      if (st != IKF_OK) return st;
+      const float* w0 = static_cast<const float*>(tw->h_data);
+      off_first[si] = cur;
+      for (int k = 0; k < n_x + 7; ++k)
+        for (int c = 0; c < W; ++c) host[cur + (size_t)k * W + c] = w0[(size_t)c * (n_x + C) + k];
+      cur += align64((size_t)(n_x + 7) * W);
+      off_soft[si] = cur;
+      if (C == 8)
+        for (int c = 0; c < W; ++c) host[cur + c] = w0[(size_t)c * (n_x + C) + n_x + 7];
+      cur += align64(W);
+      off_bfirst[si] = cur;
+      memcpy(&host[cur], tb->h_data, sizeof(float) * W);
+      cur += align64(W);
+      for (int l = 1; l < d.n_hidden; ++l) {
+        st = need(idx, base + std::to_string(2 * l) + ".weight", 0, {W, W}, &tw);
+        if (st != IKF_OK) return st;
+        st = need(idx, base + std::to_string(2 * l) + ".bias", 0, {W}, &tb);
+        if (st != IKF_OK) return st;
+        off_mid[si].push_back(cur);
+        memcpy(&host[cur], tw->h_data, sizeof(float) * (size_t)W * W);
+        cur += align64((size_t)W * W);
+        off_bmid[si].push_back(cur);
+        memcpy(&host[cur], tb->h_data, sizeof(float) * W);
+        cur += align64(W);
+      }
+      st = need(idx, base + std::to_string(2 * (n_lin - 1)) + ".weight", 0, {n_out, W}, &tw);
+      if (st != IKF_OK) return st;
+      st = need(idx, base + std::to_string(2 * (n_lin - 1)) + ".bias", 0, {n_out}, &tb);
+      if (st != IKF_OK) return st;
+      off_last[si] = cur;
+      memcpy(&host[cur], tw->h_data, sizeof(float) * (size_t)n_out * W);
+      cur += align64((size_t)n_out * W);
+      off_blast[si] = cur;
+      memcpy(&host[cur], tb->h_data, sizeof(float) * n_out);
+      cur += align64(n_out);
+      subs[si].n_x = n_x;
+      subs[si].n_out = n_out;
+    }
+  }
+  if (cur != total) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_load_weights: internal packing size mismatch");
+
+  const ikf_tensor* tM = nullptr;
+  ikf_status st = need(idx, "module_list.0.M_inv", 0, {D, D}, &tM);
+  if (st != IKF_OK) return st;
+  std::vector<float> blin(D, 0.f);
+  if (const ikf_tensor* tb = find_tensor(idx, "module_list.0.b")) {
+    if (tb->dtype != 0 || !tb->h_data) return fail(IKF_ERR_MISSING_TENSOR, "module_list.0.b has the wrong dtype");
+    int64_t numel = 1;
+    for (int k = 0; k < tb->ndim; ++k) numel *= tb->shape[k];
+    if (numel != D) return fail(IKF_ERR_MISSING_TENSOR, "size mismatch for module_list.0.b");
+    memcpy(blin.data(), tb->h_data, sizeof(float) * D);
+  }
+
+  // upload
+  if (m->arena) { (void)hipFree(m->arena); m->arena = nullptr; }
+  if (!m->d_perm_inv) IKF_HIP(hipMalloc(&m->d_perm_inv, sizeof(int) * (size_t)NB * D));
+  if (!m->d_Minv) IKF_HIP(hipMalloc(&m->d_Minv, sizeof(float) * D * D));
+  if (!m->d_blin) IKF_HIP(hipMalloc(&m->d_blin, sizeof(float) * D));
+  IKF_HIP(hipMalloc(&m->arena, sizeof(float) * total));
+  m->arena_floats = total;
+  IKF_HIP(hipMemcpy(m->arena, host.data(), sizeof(float) * total, hipMemcpyHostToDevice));
+  IKF_HIP(hipMemcpy(m->d_perm_inv, perm_host.data(), sizeof(int) * (size_t)NB * D, hipMemcpyHostToDevice));
+  IKF_HIP(hipMemcpy(m->d_Minv, tM->h_data, sizeof(float) * D * D, hipMemcpyHostToDevice));
+  IKF_HIP(hipMemcpy(m->d_blin, blin.data(), sizeof(float) * D, hipMemcpyHostToDevice));
+  for (int si = 0; si < 2 * NB; ++si) {
+    SubnetWeights& s = subs[si];
+    s.w_first_t = m->arena + off_first[si];
+    s.w_soft = m->arena + off_soft[si];
+    s.b_first = m->arena + off_bfirst[si];
+    for (int l = 0; l < 3; ++l) {
+      s.w_mid[l] = (l < (int)off_mid[si].size()) ? m->arena + off_mid[si][l] : nullptr;
+      s.b_mid[l] = (l < (int)off_bmid[si].size()) ? m->arena + off_bmid[si][l] : nullptr;
+    }
+    s.w_last = m->arena + off_last[si];
+    s.b_last = m->arena + off_blast[si];
+  }
+  m->subnets = subs;
+  m->loaded = true;
+  return IKF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// scratch
+// ---------------------------------------------------------------------------------------------------------------
+static ikf_status ensure_scratch(ikf_model* m, long long rows) {
+  long long want = rows < kMaxChunkRows ? rows : kMaxChunkRows;
+  if (want < 128) want = 128;
+  if (want <= m->chunk_rows) return IKF_OK;
+  free_scratch(m);
+  IKF_HIP(hipMalloc(&m->xbuf, sizeof(float) * (size_t)want * m->dims.D));
+  IKF_HIP(hipMalloc(&m->hA, sizeof(float) * (size_t)want * m->dims.width));
+  IKF_HIP(hipMalloc(&m->hB, sizeof(float) * (size_t)want * m->dims.width));
+  m->chunk_rows = want;
+  return IKF_OK;
+}
+
+static ikf_status ensure_exact(ikf_model* m, long long poses, long long rows) {
+  if (poses > m->exact_poses || rows > m->exact_rows) {
+    const long long np = poses > m->exact_poses ? poses : m->exact_poses;
+    const long long nr = rows > m->exact_rows ? rows : m->exact_rows;
+    free_exact(m);
+    IKF_HIP(hipMalloc(&m->ex_q, sizeof(float) * (size_t)nr * m->dims.ndof));
+    IKF_HIP(hipMalloc(&m->ex_row_valid, (size_t)nr));
+    IKF_HIP(hipMalloc(&m->ex_pose_idx, sizeof(int) * (size_t)np));
+    IKF_HIP(hipMalloc(&m->ex_solved, (size_t)np));
+    m->exact_poses = np;
+    m->exact_rows = nr;
+  }
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_reserve: null model");
+  if (max_rows < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_reserve: max_rows must be positive");
+  IKF_HIP(hipSetDevice(m->device));
+  return ensure_scratch(m, max_rows);
+}
+
+extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
+  if (variant < -1 || variant >= gemm_variant_count()) return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant");
+  m->gemm_variant = variant;
+  return IKF_OK;
+}
+
+static int pick_variant(const ikf_model* m, long long rows) {
+  if (m->gemm_variant >= 0) return m->gemm_variant;
+  const int W = m->dims.width;
+  // fill the 256 CUs: 128x128 tiles when that already gives >= 256 tiles, smaller tiles for smaller batches
+  const long long t128 = ((rows + 127) / 128) * (W / 128);
+  if (t128 >= 256) return 0;
+  const long long t12864 = ((rows + 127) / 128) * (W / 64);
+  if (t12864 >= 256) return 2;
+  return 4;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// flow inverse pass over `rows` rows (chunked); replaces nn_model(latent, c=cond, rev=True) + slice + clamp
+// ---------------------------------------------------------------------------------------------------------------
+static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
+                           float* d_q_out, hipStream_t s) {
+  ikf_status st = ensure_scratch(m, rows);
+  if (st != IKF_OK) return st;
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes;
+  for (long long r0 = 0; r0 < rows; r0 += m->chunk_rows) {
+    const long long nr = (rows - r0 < m->chunk_rows) ? rows - r0 : m->chunk_rows;
+    const int variant = pick_variant(m, nr);
+    for (int b = NB - 1; b >= 0; --b) {
+      const float* x_in = (b == NB - 1) ? d_latent + (size_t)r0 * d.D : m->xbuf;
+      for (int which = 1; which <= 2; ++which) {
+        const SubnetWeights& w = m->subnets[2 * b + which - 1];
+        const float* x_src = (which == 1) ? x_in : m->xbuf;
+        IKF_HIP(launch_first_layer(w, d, x_src, which == 1 ? 0 : d.L1, ps, r0, nr, m->hA, s));
+        float* cur = m->hA;
+        float* nxt = m->hB;
+        for (int l = 0; l < d.n_hidden - 1; ++l) {
+          IKF_HIP(launch_gemm_lrelu(variant, cur, w.w_mid[l], w.b_mid[l], nxt, nr, d.width, d.width, d.slope, s));
+          float* tmp = cur; cur = nxt; nxt = tmp;
+        }
+        CouplingArgs ca{};
+        ca.x_in = x_in;
+        ca.x_out = m->xbuf;
+        ca.perm_inv = m->d_perm_inv + (size_t)b * d.D;
+        ca.M_inv = m->d_Minv;
+        ca.b_lin = m->d_blin;
+        ca.lo = reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, lo));
+        ca.hi = reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, hi));
+        ca.q_out = d_q_out + (size_t)r0 * d.ndof;
+        ca.which = which;
+        ca.is_final = (b == 0 && which == 2) ? 1 : 0;
+        ca.clamp_limits = clamp_limits;
+        IKF_HIP(launch_last_layer_coupling(w, d, cur, ca, nr, s));
+      }
+    }
+  }
+  return IKF_OK;
+}
+
+static ikf_status check_ready(ikf_model* m, const char* fn) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, std::string(fn) + ": null model");
+  if (!m->loaded)
+    return fail(IKF_ERR_NOT_LOADED, "Model weights have not been loaded. Call load_state_dict(...)");
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_generate_approx(ikf_model* m, const float* d_poses, int pose_broadcast, const float* d_latent,
+                                          int64_t n, int clamp_to_limits, float softflow_scale, float* d_q_out,
+                                          void* stream) {
+  ikf_status st = check_ready(m, "ikf_generate_approx");
+  if (st != IKF_OK) return st;
+  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_approx: n must be >= 0");
+  if (n == 0) return IKF_OK;
+  if (!d_poses || !d_latent || !d_q_out) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_approx: null device pointer");
+  IKF_HIP(hipSetDevice(m->device));
+  PoseSource ps{d_poses, nullptr, pose_broadcast ? 1 : (long long)n, 7, softflow_scale};
+  return run_flow(m, ps, d_latent, n, clamp_to_limits, d_q_out, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// kinematics
+// ---------------------------------------------------------------------------------------------------------------
+#define IKF_KIN_PROLOGUE(fn)                                                         \
+  if (!m) return fail(IKF_ERR_NULL_POINTER, fn ": null model");                      \
+  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, fn ": n must be >= 0");               \
+  if (n == 0) return IKF_OK;                                                         \
+  IKF_HIP(hipSetDevice(m->device));                                                  \
+  hipStream_t s = static_cast<hipStream_t>(stream);
+
+extern "C" ikf_status ikf_forward_kinematics(ikf_model* m, const float* d_q, int64_t n, float* d_poses_out, void* stream) {
+  IKF_KIN_PROLOGUE("ikf_forward_kinematics")
+  if (!d_q || !d_poses_out) return fail(IKF_ERR_NULL_POINTER, "ikf_forward_kinematics: null device pointer");
+  IKF_HIP(launch_fk(m->d_chain, m->dims.ndof, d_q, n, d_poses_out, s));
+  return IKF_OK;
+}
+extern "C" ikf_status ikf_pose_error(ikf_model* m, const float* d_q, const float* d_target_poses, int64_t n,
+                                     float* d_pos_err, float* d_rot_err, void* stream) {
+  IKF_KIN_PROLOGUE("ikf_pose_error")
+  if (!d_q || !d_target_poses || !d_pos_err || !d_rot_err) return fail(IKF_ERR_NULL_POINTER, "ikf_pose_error: null device pointer");
+  IKF_HIP(launch_pose_error(m->d_chain, m->dims.ndof, d_q, d_target_poses, n, d_pos_err, d_rot_err, s));
+  return IKF_OK;
+}
+extern "C" ikf_status ikf_lm_step(ikf_model* m, const float* d_target_poses, const float* d_q, int64_t n, float* d_q_out,
+                                  void* stream) {
+  IKF_KIN_PROLOGUE("ikf_lm_step")
+  if (!d_q || !d_target_poses || !d_q_out) return fail(IKF_ERR_NULL_POINTER, "ikf_lm_step: null device pointer");
+  IKF_HIP(launch_lm_step(m->d_chain, m->dims.ndof, d_target_poses, d_q, n, d_q_out, s));
+  return IKF_OK;
+}
+extern "C" ikf_status ikf_jacobian(ikf_model* m, const float* d_q, int64_t n, float* d_jac_out, void* stream) {
+  IKF_KIN_PROLOGUE("ikf_jacobian")
+  if (!d_q || !d_jac_out) return fail(IKF_ERR_NULL_POINTER, "ikf_jacobian: null device pointer");
+  IKF_HIP(launch_jacobian(m->d_chain, m->dims.ndof, d_q, n, d_jac_out, s));
+  return IKF_OK;
+}
+extern "C" ikf_status ikf_clamp_to_joint_limits(ikf_model* m, const float* d_q, int64_t n, float* d_q_out, void* stream) {
+  IKF_KIN_PROLOGUE("ikf_clamp_to_joint_limits")
+  if (!d_q || !d_q_out) return fail(IKF_ERR_NULL_POINTER, "ikf_clamp_to_joint_limits: null device pointer");
+  IKF_HIP(launch_clamp(m->d_chain, m->dims.ndof, d_q, n, d_q_out, s));
+  return IKF_OK;
+}
+extern "C" ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, int64_t n, uint8_t* d_exceeded_out,
+                                                void* stream) {
+  IKF_KIN_PROLOGUE("ikf_joint_limits_exceeded")
+  if (!d_q || !d_exceeded_out) return fail(IKF_ERR_NULL_POINTER, "ikf_joint_limits_exceeded: null device pointer");
+  IKF_HIP(launch_limits_exceeded(m->d_chain, m->dims.ndof, d_q, n, d_exceeded_out, s));
+  return IKF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// exact IK
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t n,
+                                         const int32_t* repeat_counts, int n_rounds, int n_lm_steps,
+                                         float pos_thr, float rot_thr, ikf_latent_fn latent_fn, void* latent_user,
+                                         float* d_q_out, uint8_t* d_valid_out, int64_t* h_stats, void* stream) {
+  ikf_status st = check_ready(m, "ikf_generate_exact");
+  if (st != IKF_OK) return st;
+  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: n must be >= 0");
+  if (!repeat_counts || n_rounds < 1 || n_rounds > IKF_MAX_ROUNDS)
+    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: repeat_counts must hold 1..8 rounds");
+  if (n_lm_steps < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: n_lm_steps must be >= 1");
+  if (!latent_fn) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: latent_fn is required");
+  if (h_stats) memset(h_stats, 0, sizeof(int64_t) * 4 * n_rounds);
+  if (n == 0) return IKF_OK;
+  if (!d_target_poses || !d_q_out || !d_valid_out) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: null device pointer");
+  if (n > 0x7fffffffLL / 64) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: n too large");
+  IKF_HIP(hipSetDevice(m->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int ndof = m->dims.ndof;
+
+  IKF_HIP(hipMemsetAsync(d_q_out, 0, sizeof(float) * (size_t)n * ndof, s));  // unsolved rows stay 0.0 (:197)
+  IKF_HIP(hipMemsetAsync(d_valid_out, 0, (size_t)n, s));
+
+  long long n_active = n;
+  for (int r = 0; r < n_rounds; ++r) {
+    const int R = repeat_counts[r];
+    if (R < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: repeat counts must be >= 1");
+    st = ensure_exact(m, n, n_active * R);
+    if (st != IKF_OK) return st;
+    // active pose list = ordered indices of still-invalid poses (identity in round 0)
+    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, s));
+    if (r > 0) {
+      IKF_HIP(hipMemcpyAsync(m->h_count, m->ex_count, sizeof(int), hipMemcpyDeviceToHost, s));
+      IKF_HIP(hipStreamSynchronize(s));
+      n_active = *m->h_count;
+      if (h_stats) h_stats[4 * (r - 1) + 3] = h_stats[4 * (r - 1) + 0] - n_active;
+      if (n_active == 0) return IKF_OK;  // everything converged (:383-385, :402-408)
+    }
+    const long long rows = n_active * R;
+    const float* d_latent = latent_fn(latent_user, r, rows, m->dims.D);
+    if (!d_latent) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: latent_fn returned null");
+    PoseSource ps{d_target_poses, m->ex_pose_idx, n_active, 7, 0.0f};
+    st = run_flow(m, ps, d_latent, rows, /*clamp=*/1, m->ex_q, s);  // seeds (:188)
+    if (st != IKF_OK) return st;
+    IKF_HIP(hipMemsetAsync(m->ex_solved, 0, (size_t)n_active, s));
+    for (int it = 0; it < n_lm_steps; ++it) {
+      IKF_HIP(launch_exact_lm_iter(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, m->ex_q,
+                                   m->ex_solved, m->ex_row_valid, pos_thr, rot_thr, s));
+      IKF_HIP(launch_exact_select(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, m->ex_solved,
+                                  d_q_out, d_valid_out, s));
+    }
+    if (h_stats) {
+      h_stats[4 * r + 0] = n_active;
+      h_stats[4 * r + 1] = rows;
+      h_stats[4 * r + 2] = rows * n_lm_steps;  // upper bound: rows of poses solved early are masked out
+    }
+  }
+  if (h_stats) {
+    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, s));
+    IKF_HIP(hipMemcpyAsync(m->h_count, m->ex_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    IKF_HIP(hipStreamSynchronize(s));
+    h_stats[4 * (n_rounds - 1) + 3] = h_stats[4 * (n_rounds - 1) + 0] - *m->h_count;
+  }
+  return IKF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// measurement hook
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float* ms_out, void* stream) {
+  ikf_status st = check_ready(m, "ikf_time_gemm");
+  if (st != IKF_OK) return st;
+  if (!ms_out || rows < 1 || iters < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_time_gemm: bad argument");
+  if (m->dims.n_hidden < 2) return fail(IKF_ERR_BAD_SHAPE, "ikf_time_gemm: model has no width x width layer");
+  IKF_HIP(hipSetDevice(m->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  st = ensure_scratch(m, rows);
+  if (st != IKF_OK) return st;
+  if (rows > m->chunk_rows) rows = m->chunk_rows;
+  const SubnetWeights& w = m->subnets[0];
+  const int variant = pick_variant(m, rows);
+  hipEvent_t e0, e1;
+  IKF_HIP(hipEventCreate(&e0));
+  IKF_HIP(hipEventCreate(&e1));
+  IKF_HIP(launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width, m->dims.slope, s));
+  IKF_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i)
+    IKF_HIP(launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width,
+                              m->dims.slope, s));
+  IKF_HIP(hipEventRecord(e1, s));
+  IKF_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  IKF_HIP(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_out = ms / iters;
+  return IKF_OK;
+}

@@ -1,0 +1,90 @@
+// Internal declarations shared by the HIP translation units of libikflow_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ikflow_amd.h"
+
+namespace ikf {
+
+// ---- packed weights of one coupling subnet (device pointers into the model's weight arena) -----------------
+struct SubnetWeights {
+  const float* w_first_t;  // [in_real][width]  first Linear, transposed, softflow column dropped into w_soft
+  const float* w_soft;     // [width]           first-Linear column that multiplies the softflow scale (cond[7])
+  const float* b_first;    // [width]
+  const float* w_mid[3];   // [width][width]    hidden Linear layers (row = output feature, K contiguous)
+  const float* b_mid[3];   // [width]
+  const float* w_last;     // [out][width]      last Linear
+  const float* b_last;     // [out]
+  int n_x;                 // number of x inputs feeding the subnet (L1 for subnet1, L2 for subnet2)
+  int n_out;               // 2*L2 for subnet1, 2*L1 for subnet2
+};
+
+// ---- where the conditional (target pose) of a flow row comes from ------------------------------------------
+// pose of global row r = poses + stride * (idx ? idx[r % n_mod] : r % n_mod)
+//   batch form      : idx = null, n_mod = n,  stride = 7      (ikflow_solver.py:338)
+//   single-pose form: idx = null, n_mod = 1,  stride = 0..7   (ikflow_solver.py:333-336, y.expand)
+//   exact-IK tiling : idx = active-pose list, n_mod = n_active (ikflow_solver.py:182-186, cond.repeat((R,1)))
+struct PoseSource {
+  const float* poses;
+  const int* idx;
+  long long n_mod;
+  int stride;
+  float softflow;
+};
+
+struct FlowDims {
+  int D, L1, L2, width, n_hidden, ndof, n_pose;  // n_pose = 7 real pose entries of the conditional
+  float clamp, slope;
+};
+
+// flow_kernels.hip
+hipError_t launch_first_layer(const SubnetWeights& w, const FlowDims& d, const float* x_in, int x_off,
+                              const PoseSource& ps, long long row0, long long rows, float* h_out, hipStream_t s);
+hipError_t launch_gemm_lrelu(int variant, const float* A, const float* W, const float* bias, float* C, long long M,
+                             int N, int K, float slope, hipStream_t s);
+struct CouplingArgs {
+  const float* x_in;   // [rows][D] state before this block (latent for the first executed block)
+  float* x_out;        // [rows][D] state buffer owned by the engine
+  const int* perm_inv; // [D]   (subnet 2 only)
+  const float* M_inv;  // [D][D] (final only)
+  const float* b_lin;  // [D]    (final only)
+  const float* lo;     // [ndof] (final only)
+  const float* hi;     // [ndof]
+  float* q_out;        // [rows][ndof] (final only)
+  int which;           // 1 or 2
+  int is_final;        // last executed block, subnet 2: apply FixedLinearTransform^-1, slice, clamp
+  int clamp_limits;
+};
+hipError_t launch_last_layer_coupling(const SubnetWeights& w, const FlowDims& d, const float* h_in,
+                                      const CouplingArgs& ca, long long rows, hipStream_t s);
+int gemm_variant_count();
+const char* gemm_kernel_name();
+
+// kin_kernels.hip
+struct Chain {
+  int ndof;
+  ikf_joint joints[IKF_MAX_DOF];
+  float tool[12];
+  float lo[IKF_MAX_DOF];
+  float hi[IKF_MAX_DOF];
+};
+hipError_t launch_fk(const Chain* d_chain, int ndof, const float* q, long long n, float* poses, hipStream_t s);
+hipError_t launch_pose_error(const Chain* d_chain, int ndof, const float* q, const float* targets, long long n,
+                             float* pos_err, float* rot_err, hipStream_t s);
+hipError_t launch_lm_step(const Chain* d_chain, int ndof, const float* targets, const float* q, long long n,
+                          float* q_out, hipStream_t s);
+hipError_t launch_jacobian(const Chain* d_chain, int ndof, const float* q, long long n, float* jac, hipStream_t s);
+hipError_t launch_clamp(const Chain* d_chain, int ndof, const float* q, long long n, float* q_out, hipStream_t s);
+hipError_t launch_limits_exceeded(const Chain* d_chain, int ndof, const float* q, long long n, uint8_t* out,
+                                  hipStream_t s);
+// exact-IK round kernels
+hipError_t launch_exact_lm_iter(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx,
+                                int n_active, int repeat, float* q, const uint8_t* solved, uint8_t* row_valid,
+                                float pos_thr, float rot_thr, hipStream_t s);
+hipError_t launch_exact_select(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
+                               const uint8_t* row_valid, uint8_t* solved, float* q_out, uint8_t* valid_out,
+                               hipStream_t s);
+hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, hipStream_t s);
+
+}  // namespace ikf

@@ -1,0 +1,478 @@
+// Batched forward kinematics, pose error, Levenberg-Marquardt step and the exact-IK bookkeeping for gfx950.
+//
+// Replaces the jrl.Robot / jrl.math_utils calls on the exact-IK path (jrl is third-party, pinned 2ba7c39, not in tree):
+//   robot.forward_kinematics                          call site ikflow/ikflow_solver.py:114
+//   geodesic_distance_between_quaternions             call site ikflow/ikflow_solver.py:116
+//   robot.inverse_kinematics_step_levenburg_marquardt call site ikflow/ikflow_solver.py:205,208
+//   robot.clamp_to_joint_limits                       call site ikflow/ikflow_solver.py:101-102
+// and the Python bookkeeping of _generate_exact_ik_solutions (ikflow_solver.py:211-233): validity mask, "highest
+// valid repeat wins" selection, and the compaction of still-unsolved poses between retry rounds (:387-400).
+//
+// One thread per row; the whole chain, the 6 x ndof Jacobian and the ndof x ndof normal equations live in registers
+// (every loop is unrolled on the compile-time NDOF so nothing is runtime-indexed).  These kernels are latency/VALU
+// bound and tiny next to the flow (~3 kFLOP per row).  FK / pose error are fp32 like the reference; the LM step is
+// evaluated in fp64 internally (J^T J + 1e-4 I has condition numbers up to ~1e5, where an fp32 solve - the
+// reference's included - carries 1e-3 relative noise) and rounded to fp32 at the end.
+#include "ikf_internal.h"
+
+namespace ikf {
+
+template <typename T>
+__device__ __forceinline__ void compose(T R[9], T p[3], const float* __restrict__ pre) {
+  // (R,p) <- (R,p) * (Rf,pf),  pre = 3x4 row-major [Rf | pf]
+  T Rn[9], pn[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      Rn[3 * r + c] = R[3 * r + 0] * (T)pre[0 * 4 + c] + R[3 * r + 1] * (T)pre[1 * 4 + c] + R[3 * r + 2] * (T)pre[2 * 4 + c];
+    pn[r] = R[3 * r + 0] * (T)pre[3] + R[3 * r + 1] * (T)pre[7] + R[3 * r + 2] * (T)pre[11] + p[r];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = pn[i];
+}
+
+__device__ __forceinline__ void sincos_t(float a, float* s, float* c) { sincosf(a, s, c); }
+__device__ __forceinline__ void sincos_t(double a, double* s, double* c) { sincos(a, s, c); }
+
+template <typename T>
+__device__ __forceinline__ void apply_joint(T R[9], T p[3], int kind, const float* __restrict__ axis, T qv) {
+  const T x = (T)axis[0], y = (T)axis[1], z = (T)axis[2];
+  if (kind == 1) {
+    T s, c;
+    sincos_t(qv, &s, &c);
+    const T t = (T)1 - c;
+    T M[9] = {t * x * x + c,     t * x * y - s * z, t * x * z + s * y,
+              t * x * y + s * z, t * y * y + c,     t * y * z - s * x,
+              t * x * z - s * y, t * y * z + s * x, t * z * z + c};
+    T Rn[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        Rn[3 * r + cc] = R[3 * r + 0] * M[cc] + R[3 * r + 1] * M[3 + cc] + R[3 * r + 2] * M[6 + cc];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p[r] += (R[3 * r + 0] * x + R[3 * r + 1] * y + R[3 * r + 2] * z) * qv;
+  }
+}
+
+// Full chain walk. If RECORD, also returns each joint's world axis and world origin (taken after the joint's fixed
+// pre-transform, before its own motion) for the geometric Jacobian.
+template <typename T, int NDOF, bool RECORD>
+__device__ __forceinline__ void fk_walk(const Chain* __restrict__ ch, const T q[NDOF], T R[9], T p[3],
+                                        T axis_w[][3], T org_w[][3]) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? (T)1 : (T)0;
+  p[0] = p[1] = p[2] = (T)0;
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) {
+    compose<T>(R, p, ch->joints[j].pre);
+    if (RECORD) {
+      const float* ax = ch->joints[j].axis;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        axis_w[j][r] = R[3 * r + 0] * (T)ax[0] + R[3 * r + 1] * (T)ax[1] + R[3 * r + 2] * (T)ax[2];
+        org_w[j][r] = p[r];
+      }
+    }
+    apply_joint<T>(R, p, ch->joints[j].kind, ch->joints[j].axis, q[j]);
+  }
+  compose<T>(R, p, ch->tool);
+}
+
+__device__ __forceinline__ float sqrt_t(float a) { return sqrtf(a); }
+__device__ __forceinline__ double sqrt_t(double a) { return sqrt(a); }
+
+// rotation matrix -> (w,x,y,z): candidate built from the largest of |w|,|x|,|y|,|z| (that component positive)
+template <typename T>
+__device__ __forceinline__ void mat_to_quat(const T R[9], T qo[4]) {
+  const T m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7], m22 = R[8];
+  T qa[4];
+  qa[0] = sqrt_t(fmax((T)0, (T)1 + m00 + m11 + m22));
+  qa[1] = sqrt_t(fmax((T)0, (T)1 + m00 - m11 - m22));
+  qa[2] = sqrt_t(fmax((T)0, (T)1 - m00 + m11 - m22));
+  qa[3] = sqrt_t(fmax((T)0, (T)1 - m00 - m11 + m22));
+  int best = 0;
+  T bv = qa[0];
+#pragma unroll
+  for (int i = 1; i < 4; ++i)
+    if (qa[i] > bv) { bv = qa[i]; best = i; }
+  const T den = (T)2 * fmax(bv, (T)0.1);
+  T c0, c1, c2, c3;
+  if (best == 0)      { c0 = qa[0] * qa[0]; c1 = m21 - m12;       c2 = m02 - m20;       c3 = m10 - m01; }
+  else if (best == 1) { c0 = m21 - m12;     c1 = qa[1] * qa[1];   c2 = m10 + m01;       c3 = m02 + m20; }
+  else if (best == 2) { c0 = m02 - m20;     c1 = m10 + m01;       c2 = qa[2] * qa[2];   c3 = m12 + m21; }
+  else                { c0 = m10 - m01;     c1 = m20 + m02;       c2 = m21 + m12;       c3 = qa[3] * qa[3]; }
+  qo[0] = c0 / den; qo[1] = c1 / den; qo[2] = c2 / den; qo[3] = c3 / den;
+}
+
+__device__ __forceinline__ float geodesic_f32(const float* qa, const float* qb) {
+  const float lo = (float)(-1.0 + 1e-7), hi = (float)(1.0 - 1e-7);
+  float dot = qa[0] * qb[0] + qa[1] * qb[1] + qa[2] * qb[2] + qa[3] * qb[3];
+  dot = fminf(fmaxf(dot, lo), hi);
+  const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+  float d = 2.0f * acosf(dot);
+  float m = fmodf(d + PI_F, TWO_PI_F);
+  if (m < 0.f) m += TWO_PI_F;
+  return fabsf(m - PI_F);
+}
+
+template <int NDOF>
+__device__ __forceinline__ void load_q(const float* __restrict__ q, long long row, float out[NDOF]) {
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) out[j] = q[(size_t)row * NDOF + j];
+}
+
+template <int NDOF>
+__device__ __forceinline__ void fk_pose_f32(const Chain* __restrict__ ch, const float qv[NDOF], float pose[7]) {
+  float R[9], p[3];
+  fk_walk<float, NDOF, false>(ch, qv, R, p, nullptr, nullptr);
+  float qq[4];
+  mat_to_quat<float>(R, qq);
+  pose[0] = p[0]; pose[1] = p[1]; pose[2] = p[2];
+  pose[3] = qq[0]; pose[4] = qq[1]; pose[5] = qq[2]; pose[6] = qq[3];
+}
+
+template <int NDOF>
+__device__ __forceinline__ void pose_error_f32(const Chain* __restrict__ ch, const float qv[NDOF],
+                                               const float* __restrict__ tgt, float* pos_err, float* rot_err) {
+  float pose[7];
+  fk_pose_f32<NDOF>(ch, qv, pose);
+  const float dx = pose[0] - tgt[0], dy = pose[1] - tgt[1], dz = pose[2] - tgt[2];
+  *pos_err = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float tq[4] = {tgt[3], tgt[4], tgt[5], tgt[6]};
+  *rot_err = geodesic_f32(tq, pose + 3);
+}
+
+// One damped least-squares step in fp64: q <- clamp(q + (J^T J + 1e-4 I)^-1 J^T e)
+template <int NDOF>
+__device__ __forceinline__ void lm_step_row(const Chain* __restrict__ ch, const float* __restrict__ tgt,
+                                            float qv[NDOF]) {
+  double qd[NDOF];
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) qd[j] = (double)qv[j];
+  double R[9], p[3], axw[NDOF][3], orw[NDOF][3];
+  fk_walk<double, NDOF, true>(ch, qd, R, p, axw, orw);
+  double qc[4];
+  mat_to_quat<double>(R, qc);
+  // rotation error quaternion = q_target * conj(q_current), as roll/pitch/yaw
+  const double w1 = tgt[3], x1 = tgt[4], y1 = tgt[5], z1 = tgt[6];
+  const double w2 = qc[0], x2 = -qc[1], y2 = -qc[2], z2 = -qc[3];
+  const double ew = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+  const double ex = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+  const double ey = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
+  const double ez = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
+  double e[6];
+  e[0] = atan2(2.0 * (ew * ex + ey * ez), 1.0 - 2.0 * (ex * ex + ey * ey));
+  e[1] = asin(fmin(fmax(2.0 * (ew * ey - ez * ex), -1.0), 1.0));
+  e[2] = atan2(2.0 * (ew * ez + ex * ey), 1.0 - 2.0 * (ey * ey + ez * ez));
+  e[3] = (double)tgt[0] - p[0];
+  e[4] = (double)tgt[1] - p[1];
+  e[5] = (double)tgt[2] - p[2];
+  // Jacobian columns: revolute [axis; axis x (p_ee - origin)], prismatic [0; axis]
+  double J[6][NDOF];
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) {
+    if (ch->joints[j].kind == 1) {
+      const double rx = p[0] - orw[j][0], ry = p[1] - orw[j][1], rz = p[2] - orw[j][2];
+      J[0][j] = axw[j][0]; J[1][j] = axw[j][1]; J[2][j] = axw[j][2];
+      J[3][j] = axw[j][1] * rz - axw[j][2] * ry;
+      J[4][j] = axw[j][2] * rx - axw[j][0] * rz;
+      J[5][j] = axw[j][0] * ry - axw[j][1] * rx;
+    } else {
+      J[0][j] = J[1][j] = J[2][j] = 0.0;
+      J[3][j] = axw[j][0]; J[4][j] = axw[j][1]; J[5][j] = axw[j][2];
+    }
+  }
+  double A[NDOF][NDOF], g[NDOF];
+#pragma unroll
+  for (int a = 0; a < NDOF; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) sacc += J[r][a] * J[r][b];
+      A[a][b] = sacc + (a == b ? 1e-4 : 0.0);
+    }
+    double gs = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) gs += J[r][a] * e[r];
+    g[a] = gs;
+  }
+  // Cholesky A = L L^T (lower), in place; then forward/back substitution
+#pragma unroll
+  for (int c = 0; c < NDOF; ++c) {
+    double dsum = A[c][c];
+#pragma unroll
+    for (int k = 0; k < c; ++k) dsum -= A[c][k] * A[c][k];
+    const double lcc = sqrt(dsum);
+    A[c][c] = lcc;
+    const double inv = 1.0 / lcc;
+#pragma unroll
+    for (int r = c + 1; r < NDOF; ++r) {
+      double v = A[r][c];
+#pragma unroll
+      for (int k = 0; k < c; ++k) v -= A[r][k] * A[c][k];
+      A[r][c] = v * inv;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NDOF; ++r) {
+    double v = g[r];
+#pragma unroll
+    for (int k = 0; k < r; ++k) v -= A[r][k] * g[k];
+    g[r] = v / A[r][r];
+  }
+#pragma unroll
+  for (int r = NDOF - 1; r >= 0; --r) {
+    double v = g[r];
+#pragma unroll
+    for (int k = r + 1; k < NDOF; ++k) v -= A[k][r] * g[k];
+    g[r] = v / A[r][r];
+  }
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) {
+    const float qn = (float)(qd[j] + g[j]);
+    qv[j] = fminf(fmaxf(qn, ch->lo[j]), ch->hi[j]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// public-API kernels
+// ---------------------------------------------------------------------------------------------------------------
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_fk(const Chain* __restrict__ ch, const float* __restrict__ q, long long n,
+                                            float* __restrict__ poses) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float qv[NDOF], pose[7];
+  load_q<NDOF>(q, row, qv);
+  fk_pose_f32<NDOF>(ch, qv, pose);
+#pragma unroll
+  for (int i = 0; i < 7; ++i) poses[(size_t)row * 7 + i] = pose[i];
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_pose_error(const Chain* __restrict__ ch, const float* __restrict__ q,
+                                                    const float* __restrict__ tgt, long long n,
+                                                    float* __restrict__ pos_err, float* __restrict__ rot_err) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float qv[NDOF], pe, re;
+  load_q<NDOF>(q, row, qv);
+  pose_error_f32<NDOF>(ch, qv, tgt + (size_t)row * 7, &pe, &re);
+  pos_err[row] = pe;
+  rot_err[row] = re;
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_lm_step(const Chain* __restrict__ ch, const float* __restrict__ tgt,
+                                                 const float* __restrict__ q, long long n, float* __restrict__ q_out) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float qv[NDOF];
+  load_q<NDOF>(q, row, qv);
+  lm_step_row<NDOF>(ch, tgt + (size_t)row * 7, qv);
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) q_out[(size_t)row * NDOF + j] = qv[j];
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_jacobian(const Chain* __restrict__ ch, const float* __restrict__ q,
+                                                  long long n, float* __restrict__ jac) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float qv[NDOF];
+  load_q<NDOF>(q, row, qv);
+  float R[9], p[3], axw[NDOF][3], orw[NDOF][3];
+  fk_walk<float, NDOF, true>(ch, qv, R, p, axw, orw);
+  float* Jo = jac + (size_t)row * 6 * NDOF;
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) {
+    if (ch->joints[j].kind == 1) {
+      const float rx = p[0] - orw[j][0], ry = p[1] - orw[j][1], rz = p[2] - orw[j][2];
+      Jo[0 * NDOF + j] = axw[j][0]; Jo[1 * NDOF + j] = axw[j][1]; Jo[2 * NDOF + j] = axw[j][2];
+      Jo[3 * NDOF + j] = axw[j][1] * rz - axw[j][2] * ry;
+      Jo[4 * NDOF + j] = axw[j][2] * rx - axw[j][0] * rz;
+      Jo[5 * NDOF + j] = axw[j][0] * ry - axw[j][1] * rx;
+    } else {
+      Jo[0 * NDOF + j] = Jo[1 * NDOF + j] = Jo[2 * NDOF + j] = 0.f;
+      Jo[3 * NDOF + j] = axw[j][0]; Jo[4 * NDOF + j] = axw[j][1]; Jo[5 * NDOF + j] = axw[j][2];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_clamp(const Chain* __restrict__ ch, int ndof, const float* __restrict__ q,
+                                               long long total, float* __restrict__ q_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int j = (int)(i % ndof);
+  q_out[i] = fminf(fmaxf(q[i], ch->lo[j]), ch->hi[j]);
+}
+
+__global__ __launch_bounds__(256) void k_limits_exceeded(const Chain* __restrict__ ch, int ndof,
+                                                         const float* __restrict__ q, long long n,
+                                                         uint8_t* __restrict__ out) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  bool ex = false;
+  for (int j = 0; j < ndof; ++j) {
+    const float v = q[(size_t)row * ndof + j];
+    ex = ex || (v > ch->hi[j]) || (v < ch->lo[j]);  // strict, evaluation_utils.py:110-112
+  }
+  out[row] = ex ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// exact-IK round kernels.  Row layout of q is the reference's tile-major one: row = r * n_active + j  <->  repeat r of
+// active pose j (cond.repeat((R,1)), ikflow_solver.py:185).  Poses solved in an earlier iteration are masked instead
+// of physically compacted (rows are independent, so the results are identical to the reference's q[mask] compaction).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NDOF>
+__global__ __launch_bounds__(256) void k_exact_lm_iter(const Chain* __restrict__ ch, const float* __restrict__ poses,
+                                                       const int* __restrict__ pose_idx, int n_active, int repeat,
+                                                       float* __restrict__ q, const uint8_t* __restrict__ solved,
+                                                       uint8_t* __restrict__ row_valid, float pos_thr, float rot_thr) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= (long long)n_active * repeat) return;
+  const int j = (int)(row % n_active);
+  if (solved[j]) {
+    row_valid[row] = 0;
+    return;
+  }
+  const float* tgt = poses + (size_t)pose_idx[j] * 7;
+  float qv[NDOF];
+  load_q<NDOF>(q, row, qv);
+  lm_step_row<NDOF>(ch, tgt, qv);
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) q[(size_t)row * NDOF + k] = qv[k];
+  float pe, re;
+  pose_error_f32<NDOF>(ch, qv, tgt, &pe, &re);
+  row_valid[row] = (pe < pos_thr && re < rot_thr) ? 1 : 0;  // ikflow_solver.py:211
+}
+
+__global__ __launch_bounds__(256) void k_exact_select(int ndof, const int* __restrict__ pose_idx, int n_active,
+                                                      int repeat, const float* __restrict__ q,
+                                                      const uint8_t* __restrict__ row_valid,
+                                                      uint8_t* __restrict__ solved, float* __restrict__ q_out,
+                                                      uint8_t* __restrict__ valid_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_active || solved[j]) return;
+  // ascending scan of valid_idxs with sol_idx = idx % n_invalid: the highest valid repeat wins (ikflow_solver.py:217-222)
+  for (int r = repeat - 1; r >= 0; --r) {
+    const long long row = (long long)r * n_active + j;
+    if (row_valid[row]) {
+      const int dst = pose_idx[j];
+      for (int k = 0; k < ndof; ++k) q_out[(size_t)dst * ndof + k] = q[(size_t)row * ndof + k];
+      valid_out[dst] = 1;
+      solved[j] = 1;
+      break;
+    }
+  }
+}
+
+// ordered compaction of the indices with valid[i] == 0 (boolean-mask indexing, ikflow_solver.py:389); single workgroup
+__global__ __launch_bounds__(1024) void k_compact_invalid(const uint8_t* __restrict__ valid, long long n,
+                                                          int* __restrict__ idx_out, int* __restrict__ count_out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const long long per = (n + 1023) / 1024;
+  const long long b = (long long)t * per;
+  long long e = b + per;
+  if (e > n) e = n;
+  int c = 0;
+  for (long long i = b; i < e; ++i) c += valid[i] ? 0 : 1;
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int pos = part[t] - c;
+  for (long long i = b; i < e; ++i)
+    if (!valid[i]) idx_out[pos++] = (int)i;
+  if (t == 1023) *count_out = part[1023];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+static inline unsigned blocks_for(long long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+#define IKF_NDOF_DISPATCH(ndof, CALL) \
+  switch (ndof) {                     \
+    case 4: { constexpr int ND = 4; CALL; break; } \
+    case 5: { constexpr int ND = 5; CALL; break; } \
+    case 6: { constexpr int ND = 6; CALL; break; } \
+    case 7: { constexpr int ND = 7; CALL; break; } \
+    case 8: { constexpr int ND = 8; CALL; break; } \
+    default: return hipErrorInvalidValue;          \
+  }
+
+hipError_t launch_fk(const Chain* ch, int ndof, const float* q, long long n, float* poses, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_fk<ND>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, q, n, poses));
+  return hipGetLastError();
+}
+hipError_t launch_pose_error(const Chain* ch, int ndof, const float* q, const float* tgt, long long n, float* pe,
+                             float* re, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_pose_error<ND>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, q, tgt,
+                                             n, pe, re));
+  return hipGetLastError();
+}
+hipError_t launch_lm_step(const Chain* ch, int ndof, const float* tgt, const float* q, long long n, float* q_out,
+                          hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_lm_step<ND>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, tgt, q, n,
+                                             q_out));
+  return hipGetLastError();
+}
+hipError_t launch_jacobian(const Chain* ch, int ndof, const float* q, long long n, float* jac, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_jacobian<ND>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, q, n, jac));
+  return hipGetLastError();
+}
+hipError_t launch_clamp(const Chain* ch, int ndof, const float* q, long long n, float* q_out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const long long total = n * ndof;
+  hipLaunchKernelGGL(k_clamp, dim3(blocks_for(total, 256)), dim3(256), 0, s, ch, ndof, q, total, q_out);
+  return hipGetLastError();
+}
+hipError_t launch_limits_exceeded(const Chain* ch, int ndof, const float* q, long long n, uint8_t* out,
+                                  hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_limits_exceeded, dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, ndof, q, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_exact_lm_iter(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active,
+                                int repeat, float* q, const uint8_t* solved, uint8_t* row_valid, float pos_thr,
+                                float rot_thr, hipStream_t s) {
+  const long long rows = (long long)n_active * repeat;
+  if (rows <= 0) return hipSuccess;
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iter<ND>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch,
+                                             poses, pose_idx, n_active, repeat, q, solved, row_valid, pos_thr,
+                                             rot_thr));
+  return hipGetLastError();
+}
+hipError_t launch_exact_select(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
+                               const uint8_t* row_valid, uint8_t* solved, float* q_out, uint8_t* valid_out,
+                               hipStream_t s) {
+  if (n_active <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_exact_select, dim3(blocks_for(n_active, 256)), dim3(256), 0, s, ndof, pose_idx, n_active,
+                     repeat, q, row_valid, solved, q_out, valid_out);
+  return hipGetLastError();
+}
+hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_compact_invalid, dim3(1), dim3(1024), 0, s, valid, n, idx_out, count_out);
+  return hipGetLastError();
+}
+
+}  // namespace ikf

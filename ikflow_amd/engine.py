@@ -1,0 +1,321 @@
+"""Python face of the C-ABI engine: owns an ``ikf_model`` handle, passes torch device pointers + the current HIP
+stream through ctypes.  torch is used here only for device memory and streams."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ikflow_amd import _lib
+from ikflow_amd.model import FlowLayout, LEAKY_RELU_SLOPE
+from ikflow_amd.robots import JOINT_FIXED, Robot, rpy_to_matrix
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _raise(code: int):
+    msg = _lib.last_error()
+    if code == _lib.IKF_ERR_NOT_LOADED:
+        raise AssertionError(msg)  # the reference asserts (ikflow_solver.py:310-311)
+    if code == _lib.IKF_ERR_MISSING_TENSOR:
+        raise RuntimeError("Error(s) in loading state_dict: " + msg)
+    raise EngineError(f"libikflow_amd status {code}: {msg}")
+
+
+def _check(code: int):
+    if code != _lib.IKF_OK:
+        _raise(code)
+
+
+def fold_chain(robot: Robot) -> Tuple[List[Tuple[int, np.ndarray, np.ndarray]], np.ndarray]:
+    """Fold the fixed URDF transforms into the actuated joints: [(kind, axis, pre 3x4)], tool 3x4 (float64 math)."""
+    joints = []
+    T = np.eye(4)
+    for j in robot.joints:
+        F = np.eye(4)
+        F[:3, :3] = rpy_to_matrix(j.origin_rpy)
+        F[:3, 3] = j.origin_xyz
+        T = T @ F
+        if j.kind == JOINT_FIXED:
+            continue
+        ax = np.asarray(j.axis, dtype=np.float64)
+        ax = ax / np.linalg.norm(ax)
+        joints.append((int(j.kind), ax, T[:3, :4].copy()))
+        T = np.eye(4)
+    return joints, T[:3, :4].copy()
+
+
+def _make_desc(layout: FlowLayout, robot: Robot) -> _lib.ikf_model_desc:
+    d = _lib.ikf_model_desc()
+    d.abi_version = _lib.IKF_ABI_VERSION
+    d.nb_nodes, d.dim, d.dim_cond = layout.nb_nodes, layout.dim, layout.dim_cond
+    d.width, d.n_hidden = layout.width, layout.n_hidden
+    d.clamp, d.leaky_slope = layout.clamp, LEAKY_RELU_SLOPE
+    d.ndof = robot.ndof
+    if robot.ndof > _lib.IKF_MAX_DOF:
+        raise EngineError(f"robot has {robot.ndof} dof; the engine supports at most {_lib.IKF_MAX_DOF}")
+    for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+        d.joint_lo[i], d.joint_hi[i] = lo, hi
+    joints, tool = fold_chain(robot)
+    for i, (kind, ax, pre) in enumerate(joints):
+        d.chain[i].kind = kind
+        for k in range(3):
+            d.chain[i].axis[k] = float(ax[k])
+        for k, v in enumerate(pre.reshape(-1)):
+            d.chain[i].pre[k] = float(v)
+    for k, v in enumerate(tool.reshape(-1)):
+        d.tool[k] = float(v)
+    return d
+
+
+def _dev_index(device) -> int:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise EngineError(f"ikflow_amd runs on the GPU only; got device '{dev}' (there is no CPU path)")
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor (got {type(t)})")
+    if t.device.type != "cuda":
+        raise EngineError(f"{name} is on '{t.device}'; ikflow_amd runs on the GPU only (there is no CPU path)")
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+class Engine:
+    """One ikf_model handle on one device."""
+
+    def __init__(self, layout: FlowLayout, robot: Robot, device):
+        self.lib = _lib.load()
+        self.layout = layout
+        self.robot = robot
+        self.device = torch.device("cuda", _dev_index(device))
+        self._h = C.c_void_p()
+        desc = _make_desc(layout, robot)
+        _check(self.lib.ikf_create(C.byref(desc), self.device.index, C.byref(self._h)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self.lib.ikf_destroy(h)
+            except Exception:
+                pass
+            self._h = C.c_void_p()
+
+    # -- helpers -------------------------------------------------------------------------------------
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on_device(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        t = _f32(t, name)
+        if t.device != self.device:
+            raise EngineError(f"{name} is on {t.device} but the engine lives on {self.device}")
+        return t
+
+    # -- weights -------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, np.ndarray]) -> None:
+        """sd: {FrEIA key: numpy array (float32 / int64)} - see ikflow_amd.model for the key names."""
+        items = list(sd.items())
+        arr = (_lib.ikf_tensor * len(items))()
+        keep = []
+        for i, (k, v) in enumerate(items):
+            v = np.ascontiguousarray(v)
+            if v.dtype.kind == "f":
+                v = v.astype(np.float32, copy=False)
+                dt = 0
+            elif v.dtype.kind in "iu":
+                v = v.astype(np.int64, copy=False)
+                dt = 1
+            else:
+                continue
+            if v.ndim > 4:
+                continue
+            name = k.encode("utf-8")
+            keep.append((name, v))
+            arr[i].name = name
+            arr[i].h_data = v.ctypes.data
+            arr[i].dtype = dt
+            arr[i].ndim = v.ndim
+            for a, s in enumerate(v.shape):
+                arr[i].shape[a] = s
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_load_weights(self._h, arr, len(items)))
+        del keep
+
+    @property
+    def weights_loaded(self) -> bool:
+        return bool(self.lib.ikf_weights_loaded(self._h))
+
+    def reserve(self, max_rows: int) -> None:
+        _check(self.lib.ikf_reserve(self._h, int(max_rows)))
+
+    def set_gemm_variant(self, variant: int) -> None:
+        _check(self.lib.ikf_set_gemm_variant(self._h, int(variant)))
+
+    # -- approximate IK ------------------------------------------------------------------------------
+    def generate_approx(self, poses: torch.Tensor, latent: torch.Tensor, clamp: bool, softflow_scale: float = 0.0) -> torch.Tensor:
+        """poses [n x 7] or [7] (broadcast); latent [n x D] -> [n x ndof]."""
+        latent = self._on_device(latent, "latent")
+        poses = self._on_device(poses, "y")
+        n = latent.shape[0]
+        assert latent.ndim == 2 and latent.shape[1] == self.layout.dim, f"latent must be [n x {self.layout.dim}], got {tuple(latent.shape)}"
+        broadcast = poses.numel() == 7
+        if not broadcast:
+            assert poses.ndim == 2 and poses.shape[1] == 7 and poses.shape[0] == n, f"{poses.shape[0]} != {n}"
+        out = torch.empty((n, self.layout.ndof), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(
+                self.lib.ikf_generate_approx(
+                    self._h, poses.data_ptr(), 1 if broadcast else 0, latent.data_ptr(), n, 1 if clamp else 0,
+                    float(softflow_scale), out.data_ptr(), self._stream(),
+                )
+            )
+        return out
+
+    # -- kinematics ----------------------------------------------------------------------------------
+    def _q(self, q: torch.Tensor) -> torch.Tensor:
+        q = self._on_device(q, "q")
+        assert q.ndim == 2 and q.shape[1] == self.layout.ndof, f"q must be [n x {self.layout.ndof}], got {tuple(q.shape)}"
+        return q
+
+    def forward_kinematics(self, q: torch.Tensor) -> torch.Tensor:
+        q = self._q(q)
+        out = torch.empty((q.shape[0], 7), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_forward_kinematics(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def pose_error(self, q: torch.Tensor, target_poses: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        q = self._q(q)
+        tp = self._on_device(target_poses, "target_poses")
+        assert tp.shape == (q.shape[0], 7)
+        pe = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
+        re = torch.empty_like(pe)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_pose_error(self._h, q.data_ptr(), tp.data_ptr(), q.shape[0], pe.data_ptr(), re.data_ptr(), self._stream()))
+        return pe, re
+
+    def lm_step(self, target_poses: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+        q = self._q(q)
+        tp = self._on_device(target_poses, "target_poses")
+        assert tp.shape == (q.shape[0], 7)
+        out = torch.empty_like(q)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_lm_step(self._h, tp.data_ptr(), q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def jacobian(self, q: torch.Tensor) -> torch.Tensor:
+        q = self._q(q)
+        out = torch.empty((q.shape[0], 6, self.layout.ndof), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_jacobian(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def clamp_to_joint_limits(self, q: torch.Tensor) -> torch.Tensor:
+        q = self._q(q)
+        out = torch.empty_like(q)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_clamp_to_joint_limits(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+        return out
+
+    def joint_limits_exceeded(self, q: torch.Tensor) -> torch.Tensor:
+        q = self._q(q)
+        out = torch.empty(q.shape[0], dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_joint_limits_exceeded(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+        return out.to(torch.bool)
+
+    # -- exact IK ------------------------------------------------------------------------------------
+    def generate_exact(
+        self,
+        target_poses: torch.Tensor,
+        repeat_counts: Sequence[int],
+        pos_error_threshold: float,
+        rot_error_threshold: float,
+        latents: Optional[Sequence[torch.Tensor]] = None,
+        n_lm_steps: int = 3,
+        return_stats: bool = False,
+    ):
+        """Returns (solutions [n x ndof] f32, valids [n] bool) (+ stats [rounds x 4] if asked).
+
+        ``latents``: optional per-round latent tensors ([>= n_r*R_r x D], tile-major) for parity runs; when None each
+        round draws ``torch.randn((n_tiled, D), device=...)`` exactly like draw_latent() (ikflow_solver.py:187)."""
+        tp = self._on_device(target_poses, "target_poses")
+        assert tp.ndim == 2 and tp.shape[1] == 7, f"target_poses must be of shape [n x 7], got {tuple(tp.shape)}"
+        n = tp.shape[0]
+        D = self.layout.dim
+        nr = len(repeat_counts)
+        sols = torch.empty((n, self.layout.ndof), dtype=torch.float32, device=self.device)
+        valid = torch.empty(n, dtype=torch.uint8, device=self.device)
+        keep: List[torch.Tensor] = []
+        err: List[BaseException] = []
+
+        def _latent_cb(_user, rnd, rows, dim):
+            try:
+                if latents is not None:
+                    lt = self._on_device(latents[rnd], f"latents[{rnd}]")
+                    assert lt.ndim == 2 and lt.shape[1] == dim and lt.shape[0] >= rows, (
+                        f"latents[{rnd}] must be at least [{rows} x {dim}], got {tuple(lt.shape)}"
+                    )
+                else:
+                    lt = 1.0 * torch.randn((rows, dim), device=self.device)
+                keep.append(lt)
+                return lt.data_ptr()
+            except BaseException as e:  # never let an exception cross the C boundary
+                err.append(e)
+                return 0
+
+        cb = _lib.LATENT_FN(_latent_cb)
+        rc = (C.c_int32 * nr)(*[int(r) for r in repeat_counts])
+        stats = (C.c_int64 * (4 * nr))()
+        with torch.cuda.device(self.device):
+            code = self.lib.ikf_generate_exact(
+                self._h, tp.data_ptr(), n, rc, nr, int(n_lm_steps), float(pos_error_threshold),
+                float(rot_error_threshold), cb, None, sols.data_ptr(), valid.data_ptr(),
+                stats if return_stats else None, self._stream(),
+            )
+        if err:
+            raise err[0]
+        _check(code)
+        # latents must outlive the enqueued kernels
+        if keep:
+            torch.cuda.current_stream(self.device).synchronize()
+        out = (sols, valid.to(torch.bool))
+        if return_stats:
+            return out + (np.array(list(stats), dtype=np.int64).reshape(nr, 4),)
+        return out
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def time_gemm(self, rows: int, iters: int) -> float:
+        ms = C.c_float(0.0)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_time_gemm(self._h, int(rows), int(iters), C.byref(ms), self._stream()))
+        return float(ms.value)
+
+    def dominant_kernel_name(self) -> str:
+        return self.lib.ikf_dominant_kernel_name().decode()
+
+
+# ---------------------------------------------------------------------------------------------------
+# kinematics-only engines for Robot.forward_kinematics & co (no flow weights needed)
+# ---------------------------------------------------------------------------------------------------
+_KIN_CACHE: Dict[Tuple[str, int], Engine] = {}
+
+
+def kinematics_engine_for(robot: Robot, device=None) -> Engine:
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if not torch.cuda.is_available():
+        raise EngineError("no GPU visible: ikflow_amd kinematics run on the MI355X only (there is no CPU path)")
+    key = (robot.name, _dev_index(dev))
+    if key not in _KIN_CACHE:
+        lay = FlowLayout(nb_nodes=1, dim=max(robot.ndof, 2), dim_cond=8, width=256, n_hidden=1, clamp=2.5, ndof=robot.ndof)
+        _KIN_CACHE[key] = Engine(lay, robot, dev)
+    return _KIN_CACHE[key]

@@ -1,0 +1,207 @@
+"""Robot descriptions for the IK hot path: serial kinematic chains + joint limits.
+
+The reference takes these from the third-party package ``jrl`` (pinned at git 2ba7c39, not in
+/root/reference, not installed): call sites ``ikflow/ikflow_solver.py:102,114,205,208``,
+``ikflow/model.py:314``, ``ikflow/evaluation_utils.py:86``.  What is restated here is only what the hot
+path reads from a ``jrl.Robot``: ``name``, ``ndof``, ``actuated_joints_limits`` and the URDF chain from
+the base link to the end-effector link.  The chains come from the robots' public URDFs.
+
+Pins held by the reference's own tests:
+  * Panda joint limits                         tests/model_test.py:27-44
+  * Panda FK(q=0) = [0.088,0,0.926, 0,0.92387953,0.38268343,0]   tests/evaluation_utils_test.py:20-24
+    (reproduced only with ``panda_hand`` as the end-effector link - see tests/test_oracle_golden.py)
+FetchArm / Fetch are restated from the public Fetch URDF and are NOT pinned by any reference test.
+
+The numerical methods of a Robot (FK, Jacobian, LM step, clamping) are HIP kernels reached through the
+C-ABI (``ikflow_amd/csrc``); this module only holds the description and forwards to the engine.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+JOINT_FIXED = 0
+JOINT_REVOLUTE = 1
+JOINT_PRISMATIC = 2
+
+
+@dataclass(frozen=True)
+class Joint:
+    """One URDF joint on the base->end-effector chain: parent_T_child = T(origin_xyz, origin_rpy) * motion(q)."""
+
+    name: str
+    kind: int  # JOINT_FIXED / JOINT_REVOLUTE / JOINT_PRISMATIC
+    origin_xyz: Tuple[float, float, float]
+    origin_rpy: Tuple[float, float, float] = (0.0, 0.0, 0.0)
+    axis: Tuple[float, float, float] = (0.0, 0.0, 1.0)
+    limits: Optional[Tuple[float, float]] = None  # (lower, upper), actuated joints only
+
+    @property
+    def actuated(self) -> bool:
+        return self.kind != JOINT_FIXED
+
+
+def rpy_to_matrix(rpy: Sequence[float]) -> np.ndarray:
+    """URDF fixed-axis roll/pitch/yaw -> 3x3 rotation (R = Rz(yaw) Ry(pitch) Rx(roll)), float64."""
+    r, p, y = (float(v) for v in rpy)
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return np.array(
+        [
+            [cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+            [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+            [-sp, cp * sr, cp * cr],
+        ],
+        dtype=np.float64,
+    )
+
+
+class Robot:
+    """Description of a serial arm + the jrl.Robot methods the hot path calls.
+
+    Mirrors the part of ``jrl.robot.Robot`` that ``ikflow`` touches (see module docstring).  Tensor
+    methods run on the GPU engine (``ikflow_amd._lib``); they never fall back to CPU arithmetic.
+    """
+
+    def __init__(self, name: str, joints: Sequence[Joint]):
+        self._name = name
+        self._joints: Tuple[Joint, ...] = tuple(joints)
+        lims = [j.limits for j in self._joints if j.actuated]
+        assert all(l is not None for l in lims), "every actuated joint needs limits"
+        self._limits: List[Tuple[float, float]] = [(float(l[0]), float(l[1])) for l in lims]
+
+    # -- description ---------------------------------------------------------------------------------
+    @property
+    def name(self) -> str:
+        return self._name
+
+    @property
+    def ndof(self) -> int:
+        return len(self._limits)
+
+    @property
+    def actuated_joints_limits(self) -> List[Tuple[float, float]]:
+        return list(self._limits)
+
+    @property
+    def joints(self) -> Tuple[Joint, ...]:
+        return self._joints
+
+    def __str__(self) -> str:
+        return f"<Robot[{self._name}] ndof={self.ndof}>"
+
+    def chain_table(self) -> np.ndarray:
+        """Pack the chain for the C-ABI: one row of 16 float32 per joint.
+
+        row = [kind, ax, ay, az, R00..R02, tx, R10..R12, ty, R20..R22, tz]  (fixed origin transform 3x4)
+        """
+        rows = np.zeros((len(self._joints), 16), dtype=np.float32)
+        for i, j in enumerate(self._joints):
+            R = rpy_to_matrix(j.origin_rpy)
+            ax = np.asarray(j.axis, dtype=np.float64)
+            n = np.linalg.norm(ax)
+            ax = ax / n if n > 0 else ax
+            rows[i, 0] = float(j.kind)
+            rows[i, 1:4] = ax
+            for r in range(3):
+                rows[i, 4 + 4 * r : 7 + 4 * r] = R[r]
+                rows[i, 7 + 4 * r] = j.origin_xyz[r]
+        return rows
+
+    # -- sampling helpers (host side, numpy; used by tests/bench to make reachable target poses) ------
+    def sample_joint_angles(self, n: int, joint_limit_eps: float = 0.0, rng: Optional[np.random.Generator] = None):
+        """Uniform joint samples inside the limits shrunk by joint_limit_eps
+        (dataset convention of scripts/build_dataset.py:186: eps = deg2rad(0.25))."""
+        rng = np.random.default_rng(0) if rng is None else rng
+        lo = np.array([l[0] for l in self._limits]) + joint_limit_eps
+        hi = np.array([l[1] for l in self._limits]) - joint_limit_eps
+        return (lo + (hi - lo) * rng.random((n, self.ndof))).astype(np.float32)
+
+    # -- engine-backed tensor methods (jrl.Robot API surface used by ikflow) --------------------------
+    def _engine(self, like):
+        from ikflow_amd.engine import kinematics_engine_for
+
+        return kinematics_engine_for(self, getattr(like, "device", None))
+
+    def forward_kinematics(self, q):
+        """[n x ndof] joint angles -> [n x 7] poses (x,y,z,qw,qx,qy,qz). ikflow_solver.py:114."""
+        return self._engine(q).forward_kinematics(q)
+
+    def clamp_to_joint_limits(self, q):
+        """Per-joint clamp to [lower, upper]; returns a new tensor. ikflow_solver.py:101-102."""
+        return self._engine(q).clamp_to_joint_limits(q)
+
+    def inverse_kinematics_step_levenburg_marquardt(self, target_poses, q):
+        """One damped-least-squares step (lambda=1e-4, alpha=1, clamped). ikflow_solver.py:205,208."""
+        return self._engine(q).lm_step(target_poses, q)
+
+    def jacobian(self, q):
+        """[n x ndof] -> [n x 6 x ndof] geometric Jacobian, rows = [angular(3); linear(3)]."""
+        return self._engine(q).jacobian(q)
+
+
+_HALF_PI = math.pi / 2.0
+
+
+def Panda() -> Robot:
+    """Franka Emika Panda, base ``panda_link0`` -> end effector ``panda_hand`` (public franka_description URDF).
+
+    Limits: reference tests/model_test.py:27-44.
+    """
+    z = (0.0, 0.0, 1.0)
+    return Robot(
+        "panda",
+        [
+            Joint("panda_joint1", JOINT_REVOLUTE, (0.0, 0.0, 0.333), (0.0, 0.0, 0.0), z, (-2.8973, 2.8973)),
+            Joint("panda_joint2", JOINT_REVOLUTE, (0.0, 0.0, 0.0), (-_HALF_PI, 0.0, 0.0), z, (-1.7628, 1.7628)),
+            Joint("panda_joint3", JOINT_REVOLUTE, (0.0, -0.316, 0.0), (_HALF_PI, 0.0, 0.0), z, (-2.8973, 2.8973)),
+            Joint("panda_joint4", JOINT_REVOLUTE, (0.0825, 0.0, 0.0), (_HALF_PI, 0.0, 0.0), z, (-3.0718, -0.0698)),
+            Joint("panda_joint5", JOINT_REVOLUTE, (-0.0825, 0.384, 0.0), (-_HALF_PI, 0.0, 0.0), z, (-2.8973, 2.8973)),
+            Joint("panda_joint6", JOINT_REVOLUTE, (0.0, 0.0, 0.0), (_HALF_PI, 0.0, 0.0), z, (-0.0175, 3.7525)),
+            Joint("panda_joint7", JOINT_REVOLUTE, (0.088, 0.0, 0.0), (_HALF_PI, 0.0, 0.0), z, (-2.8973, 2.8973)),
+            Joint("panda_joint8", JOINT_FIXED, (0.0, 0.0, 0.107)),
+            Joint("panda_hand_joint", JOINT_FIXED, (0.0, 0.0, 0.0), (0.0, 0.0, -math.pi / 4.0)),
+        ],
+    )
+
+
+def _fetch_arm_joints() -> List[Joint]:
+    x, y, zz = (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)
+    pi = math.pi
+    return [
+        Joint("shoulder_pan_joint", JOINT_REVOLUTE, (0.119525, 0.0, 0.34858), axis=zz, limits=(-1.6056, 1.6056)),
+        Joint("shoulder_lift_joint", JOINT_REVOLUTE, (0.117, 0.0, 0.06), axis=y, limits=(-1.221, 1.518)),
+        Joint("upperarm_roll_joint", JOINT_REVOLUTE, (0.219, 0.0, 0.0), axis=x, limits=(-pi, pi)),
+        Joint("elbow_flex_joint", JOINT_REVOLUTE, (0.133, 0.0, 0.0), axis=y, limits=(-2.251, 2.251)),
+        Joint("forearm_roll_joint", JOINT_REVOLUTE, (0.197, 0.0, 0.0), axis=x, limits=(-pi, pi)),
+        Joint("wrist_flex_joint", JOINT_REVOLUTE, (0.1245, 0.0, 0.0), axis=y, limits=(-2.16, 2.16)),
+        Joint("wrist_roll_joint", JOINT_REVOLUTE, (0.1385, 0.0, 0.0), axis=x, limits=(-pi, pi)),
+        Joint("gripper_axis", JOINT_FIXED, (0.16645, 0.0, 0.0)),
+    ]
+
+
+def FetchArm() -> Robot:
+    """Fetch's 7-joint arm, base ``torso_lift_link`` -> ``gripper_link`` (public fetch_description URDF;
+    continuous joints limited to [-pi, pi]).  Unpinned against jrl."""
+    return Robot("fetch_arm", _fetch_arm_joints())
+
+
+def Fetch() -> Robot:
+    """Fetch with the prismatic torso lift (8 dof), base ``base_link`` -> ``gripper_link``. Unpinned."""
+    torso = Joint(
+        "torso_lift_joint", JOINT_PRISMATIC, (-0.086875, 0.0, 0.37743), axis=(0.0, 0.0, 1.0), limits=(0.0, 0.38615)
+    )
+    return Robot("fetch", [torso] + _fetch_arm_joints())
+
+
+_ROBOTS = {"panda": Panda, "fetch_arm": FetchArm, "fetch": Fetch}
+
+
+def get_robot(robot_name: str) -> Robot:
+    """Mirror of ``jrl.robots.get_robot`` for the robots whose released models are on the hot path
+    (ikflow/model_loading.py:81-83)."""
+    if robot_name not in _ROBOTS:
+        raise ValueError(f"Unable to find robot '{robot_name}' (available: {sorted(_ROBOTS)})")
+    return _ROBOTS[robot_name]()

@@ -1,0 +1,153 @@
+/*
+ * ikflow_amd.h - C-ABI of the MI355X (gfx950) IKFlow inference engine.
+ *
+ * This is the drop-in boundary for the hot path of jstmn/ikflow:
+ *     IKFlowSolver.generate_ik_solutions()        ikflow/ikflow_solver.py:254-343
+ *     IKFlowSolver.generate_exact_ik_solutions()  ikflow/ikflow_solver.py:345-411
+ * The reference has no FFI of its own (pure Python on FrEIA / jrl / torch); the entry points below are what a
+ * ctypes binding inside ikflow/ikflow_solver.py would call instead of `self.nn_model(latent, c=cond, rev=True)`
+ * (:98), `robot.forward_kinematics` (:114), `geodesic_distance_between_quaternions` (:116),
+ * `robot.inverse_kinematics_step_levenburg_marquardt` (:205,208) and `robot.clamp_to_joint_limits` (:102).
+ * INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - plain C types only: no torch / HIP types in signatures; a stream is passed as `void*` (hipStream_t, may be NULL
+ *     for the default stream).
+ *   - pointers prefixed d_ are DEVICE pointers owned by the caller; h_ are HOST pointers.
+ *   - all matrices are row-major fp32; poses are [x y z qw qx qy qz] (ikflow README.md:76).
+ *   - every function returns an ikf_status; ikf_last_error() returns a thread-local message for the last failure.
+ *   - a handle is NOT thread-safe; use one handle per device.  Work is enqueued on the given stream; the approx
+ *     path never synchronises, the exact path synchronises once per retry round to read a 4-byte count.
+ *   - the library owns: the handle, the packed weights and its scratch.  ikf_reserve() pre-sizes scratch so that
+ *     steady-state calls allocate nothing.
+ */
+#ifndef IKFLOW_AMD_H
+#define IKFLOW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IKF_ABI_VERSION 1
+#define IKF_MAX_DOF 8     /* actuated joints on the chain                      */
+#define IKF_MAX_DIM 16    /* flow width D (dim_latent_space)                   */
+#define IKF_MAX_ROUNDS 8  /* len(repeat_counts)                                */
+
+typedef enum ikf_status {
+  IKF_OK = 0,
+  IKF_ERR_NULL_POINTER = 1,
+  IKF_ERR_BAD_SHAPE = 2,        /* dimension outside what the kernels are built for          */
+  IKF_ERR_NOT_LOADED = 3,       /* weights not loaded (== the reference's assert, :310-311)   */
+  IKF_ERR_MISSING_TENSOR = 4,   /* a state_dict key is absent or has the wrong shape         */
+  IKF_ERR_HIP = 5,              /* a HIP runtime call failed; see ikf_last_error()           */
+  IKF_ERR_NO_DEVICE = 6,        /* no gfx950 device visible                                  */
+  IKF_ERR_BAD_ARGUMENT = 7
+} ikf_status;
+
+/* One actuated joint of the serial chain, with the fixed transforms that precede it already folded in
+ * (replaces the per-joint walk of jrl.Robot.forward_kinematics; call site ikflow_solver.py:114). */
+typedef struct ikf_joint {
+  int32_t kind;          /* 1 = revolute, 2 = prismatic                                   */
+  float axis[3];         /* unit axis in the joint frame                                  */
+  float pre[12];         /* 3x4 row-major fixed transform applied before the joint motion */
+} ikf_joint;
+
+/* Replaces IkflowModelParameters (ikflow/model.py:17-41) + the jrl.Robot description (ikflow_solver.py:33). */
+typedef struct ikf_model_desc {
+  int32_t abi_version;        /* IKF_ABI_VERSION                                                    */
+  int32_t nb_nodes;           /* coupling blocks                     model.py:338                   */
+  int32_t dim;                /* D = dim_latent_space                ikflow_solver.py:54            */
+  int32_t dim_cond;           /* 8 (softflow) or 7                   ikflow_solver.py:51-53         */
+  int32_t width;              /* coeff_fn_internal_size              model.py:297                   */
+  int32_t n_hidden;           /* coeff_fn_config (1..4)              model.py:59                    */
+  float clamp;                /* rnvp_clamp                          model.py:347                   */
+  float leaky_slope;          /* 0.01                                model.py:63                    */
+  int32_t ndof;               /* robot.ndof                                                         */
+  float joint_lo[IKF_MAX_DOF];
+  float joint_hi[IKF_MAX_DOF];
+  ikf_joint chain[IKF_MAX_DOF];
+  float tool[12];             /* 3x4 fixed transform after the last joint (end-effector frame)      */
+} ikf_model_desc;
+
+/* One named tensor of the reference's state_dict (FrEIA GraphINN key names, ikflow_solver.py:413-429). */
+typedef struct ikf_tensor {
+  const char* name;     /* e.g. "module_list.2.subnet1.0.weight"                 */
+  const void* h_data;   /* host pointer; fp32 (dtype 0) or int64 (dtype 1)       */
+  int32_t dtype;        /* 0 = float32, 1 = int64                                */
+  int32_t ndim;
+  int64_t shape[4];
+} ikf_tensor;
+
+typedef struct ikf_model ikf_model; /* opaque */
+
+/* -- lifetime ---------------------------------------------------------------------------------------------- */
+ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_model** out);
+void ikf_destroy(ikf_model* m);
+const char* ikf_last_error(void);
+int ikf_abi_version(void);
+
+/* Replaces IKFlowSolver.load_state_dict (ikflow_solver.py:413-429): packs the tensors once into the kernels'
+ * HBM layout.  Required keys: module_list.0.M_inv [D,D]; optional module_list.0.b [1,D]; per block i:
+ * module_list.{2i+1}.perm_inv [D] (int64), module_list.{2i+2}.subnet{1,2}.{0,2,..}.{weight,bias}. */
+ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors);
+int ikf_weights_loaded(const ikf_model* m);
+
+/* Pre-size scratch for batches of up to max_rows flow rows (and the LM state for exact IK). */
+ikf_status ikf_reserve(ikf_model* m, int64_t max_rows);
+
+/* -- approximate IK: replaces IKFlowSolver._run_inference (ikflow_solver.py:85-110) ----------------------- */
+/* d_poses: [n x 7], or a single pose [7] when pose_broadcast != 0 (the `y.expand((n,7))` form, :333-336).
+ * d_latent: [n x D].  d_q_out: [n x ndof].  clamp_to_limits: robot.clamp_to_joint_limits (:101-102).
+ * softflow_scale: the 8th conditional entry (always 0.0 at inference, :335-338). */
+ikf_status ikf_generate_approx(ikf_model* m, const float* d_poses, int pose_broadcast, const float* d_latent,
+                               int64_t n, int clamp_to_limits, float softflow_scale, float* d_q_out, void* stream);
+
+/* -- kinematics: replace the jrl.Robot calls ---------------------------------------------------------------- */
+/* robot.forward_kinematics (ikflow_solver.py:114): [n x ndof] -> [n x 7]. */
+ikf_status ikf_forward_kinematics(ikf_model* m, const float* d_q, int64_t n, float* d_poses_out, void* stream);
+/* IKFlowSolver._calculate_pose_error (ikflow_solver.py:112-117): L2 position error and quaternion geodesic. */
+ikf_status ikf_pose_error(ikf_model* m, const float* d_q, const float* d_target_poses, int64_t n,
+                          float* d_pos_err, float* d_rot_err, void* stream);
+/* robot.inverse_kinematics_step_levenburg_marquardt(target_poses, q) with jrl defaults (lambda 1e-4, alpha 1,
+ * clamped) (ikflow_solver.py:205,208). d_q_out may alias d_q. */
+ikf_status ikf_lm_step(ikf_model* m, const float* d_target_poses, const float* d_q, int64_t n, float* d_q_out,
+                       void* stream);
+/* robot.jacobian: [n x ndof] -> [n x 6 x ndof], rows = angular(3), linear(3). */
+ikf_status ikf_jacobian(ikf_model* m, const float* d_q, int64_t n, float* d_jac_out, void* stream);
+/* robot.clamp_to_joint_limits (ikflow_solver.py:101-102). d_q_out may alias d_q. */
+ikf_status ikf_clamp_to_joint_limits(ikf_model* m, const float* d_q, int64_t n, float* d_q_out, void* stream);
+/* evaluation_utils.calculate_joint_limits_exceeded (evaluation_utils.py:100-112): strict inequalities. */
+ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, int64_t n, uint8_t* d_exceeded_out,
+                                     void* stream);
+
+/* -- exact IK: replaces generate_exact_ik_solutions + _generate_exact_ik_solutions (:119-247, :345-411) ----- */
+/* Callback that supplies the latent for retry round `round`: must fill (or return a pointer to) a device buffer of
+ * [rows x D] fp32 laid out tile-major exactly as the reference draws it (`draw_latent(..., (n_tiled, D))`, :187).
+ * The Python shim draws it with torch.randn on the device - the same generator call the reference makes. */
+typedef const float* (*ikf_latent_fn)(void* user, int round, int64_t rows, int dim);
+
+/* d_target_poses [n x 7]; repeat_counts[n_rounds]; thresholds as in :349-350.
+ * Outputs: d_q_out [n x ndof] (rows never solved stay 0.0, :197), d_valid_out [n] (0/1).
+ * n_lm_steps: the reference's n_opt_steps_max = 3 (:364).
+ * h_stats (nullable, 4*n_rounds int64): per round {poses entering, flow rows, LM row-iterations, poses solved}. */
+ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t n, const int32_t* repeat_counts,
+                              int n_rounds, int n_lm_steps, float pos_error_threshold, float rot_error_threshold,
+                              ikf_latent_fn latent_fn, void* latent_user, float* d_q_out, uint8_t* d_valid_out,
+                              int64_t* h_stats, void* stream);
+
+/* -- measurement hooks (bench.py / tests) -------------------------------------------------------------------- */
+/* Time `iters` launches of the dominant kernel (the width x width fused Linear+LeakyReLU contraction) on M rows with
+ * hipEvents on `stream`; returns average milliseconds per launch in *ms_out. */
+ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float* ms_out, void* stream);
+/* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
+const char* ikf_dominant_kernel_name(void);
+/* Select the contraction kernel variant (tile shape); 0 = default. Returns IKF_ERR_BAD_ARGUMENT if unknown. */
+ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IKFLOW_AMD_H */
