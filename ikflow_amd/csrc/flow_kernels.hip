@@ -11,6 +11,8 @@
 //                            [:, :ndof], clamp_to_joint_limits   (ikflow_solver.py:99-102)
 //
 // All arithmetic is fp32 (ikflow/config.py:8); the MFMA used is the exact-f32 one (bitwise an fmaf chain).
+#include <type_traits>
+
 #include "ikf_internal.h"
 
 namespace ikf {
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_gemm_lrelu(const floa
     __syncthreads();
   }
 
-  // epilogue: bias + LeakyReLU, direct stores (each half-wave writes 128 contiguous bytes per register)
+  // epilogue: bias + LeakyReLU, direct unpredicated stores (each half-wave writes 128 contiguous bytes per register).
+  // A per-store `row < M` predicate makes hipcc put an s_waitcnt vmcnt(0) in front of EVERY store (stores count in
+  // vmcnt on gfx950), serialising 64 stores per wave - so the output buffer is required to be row-padded instead.
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -235,10 +239,244 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_gemm_lrelu(const floa
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
         float v = acc[i][j][r] + bv;
         v = v > 0.f ? v : v * slope;
-        if (row < M) C[(size_t)row * N + col] = v;
+        C[(size_t)row * N + col] = v;  // C has its rows padded to a multiple of BM (engine scratch): no predicate
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Software-pipelined form of the same contraction: 3 LDS stages, ONE barrier per K tile placed in the middle of the
+// tile's MFMA stream, fragments for the next k-group (and for the next tile's first k-group) are read while the
+// current group's MFMAs issue.  With one wave per SIMD and 64-cycle MFMAs, everything that is not an MFMA (global
+// loads for tile kt+2, ds_write of tile kt+1, the barrier, ds_read of the next fragments) sits in the shadow of >= 16
+// queued-up MFMAs, so the matrix pipe never drains inside the K loop.
+//   hazards: tile kt+1 is written to stage (kt+1)%3 during iteration kt; that stage last held tile kt-2, whose
+//   fragment reads ended in iteration kt-2 and are separated from these writes by iteration kt-1's barrier.  The
+//   reads of tile kt+1's first fragments come after iteration kt's barrier, i.e. after every wave's writes.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void k_gemm_lrelu_p3(const float* __restrict__ A,
+                                                                          const float* __restrict__ W,
+                                                                          const float* __restrict__ bias,
+                                                                          float* __restrict__ C, int M, int N, int K,
+                                                                          float slope) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int LDK = BK + 4;
+  constexpr int KQ = BK / 4;
+  constexpr int A_F4 = BM * KQ / NT;
+  constexpr int B_F4 = BN * KQ / NT;
+  constexpr int RS = NT / KQ;
+  constexpr int NKK = BK / 8;  // k-groups per tile (each = one float4 fragment per 32-row block = 4 MFMAs per (i,j))
+  constexpr int STAGE = (BM + BN) * LDK;
+  static_assert(BM * KQ % NT == 0 && BN * KQ % NT == 0 && NT % KQ == 0, "tile/threads mismatch");
+  static_assert(NKK % 2 == 0 && NKK >= 2, "fragment double-buffering needs an even number of k-groups");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][LDK]
+
+  const int tiles_n = N / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = (wave / WAVES_N) * WM, wn = (wave % WAVES_N) * WN;
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int row_t = t / KQ, kq_t = (t % KQ) * 4;
+  const float* a_src[A_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    int gr = m0 + row_t + i * RS;
+    gr = gr < M ? gr : M - 1;
+    a_src[i] = A + (size_t)gr * K + kq_t;
+  }
+  const float* b_base = W + (size_t)(n0 + row_t) * K + kq_t;
+  const int lds_t = row_t * LDK + kq_t;
+  const int fragA = (wm + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int fragB = BM * LDK + (wn + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int KT = K / BK;
+
+  floatx4 ra[A_F4], rb[B_F4];
+  floatx4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+
+#define IKF_GLOAD(koff)                                                                                           \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const floatx4*>(a_src[i] + (koff)); \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
+        rb[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (koff));                        \
+  }
+#define IKF_LSTORE(stage)                                                                                         \
+  {                                                                                                               \
+    float* sp_ = smem + (stage) * STAGE + lds_t;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp_ + i * RS * LDK) = ra[i];      \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
+        *reinterpret_cast<floatx4*>(sp_ + BM * LDK + i * RS * LDK) = rb[i];                                       \
+  }
+#define IKF_FRAG(FA, FB, stage, kk)                                                                               \
+  {                                                                                                               \
+    const float* sp_ = smem + (stage) * STAGE + (kk) * 8;                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = *reinterpret_cast<const floatx4*>(sp_ + fragA + i * 32 * LDK); \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = *reinterpret_cast<const floatx4*>(sp_ + fragB + j * 32 * LDK); \
+  }
+#define IKF_MFMA4(FA, FB)                                                                                         \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0);                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0);                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0);                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0);                     \
+    }                                                                                                             \
+  }
+
+  // One K tile.  HAS1/HAS2 (tile kt+1 / kt+2 exist) are compile-time so the steady-state body is branch-free: one
+  // scheduling region before the barrier and one after it, in which the sched_group_barrier sequence below pins a
+  // k-MFMA : 1-memory-op interleave (all ds_write / global_load / ds_read sit in MFMA shadows).
+  auto k_tile = [&](auto has1_c, auto has2_c, int kt, int cur, int nxt) {
+    constexpr bool HAS1 = decltype(has1_c)::value, HAS2 = decltype(has2_c)::value;
+    // ---- first half: k-groups 0 .. NKK/2-1; stage tile kt+1 into LDS; fetch tile kt+2 into registers
+#pragma unroll
+    for (int kk = 0; kk < NKK / 2; ++kk) {
+      if (kk & 1) { IKF_FRAG(fa0, fb0, cur, kk + 1) } else { IKF_FRAG(fa1, fb1, cur, kk + 1) }
+      if (kk & 1) { IKF_MFMA4(fa1, fb1) } else { IKF_MFMA4(fa0, fb0) }
+      if (kk == 0) {
+        if (HAS1) IKF_LSTORE(nxt)
+        if (HAS2) IKF_GLOAD((kt + 2) * BK)
+      }
+    }
+    {
+      constexpr int n_mfma = (NKK / 2) * MI * NI * 4;
+      constexpr int n_mem = (HAS1 ? A_F4 + B_F4 : 0) + (HAS2 ? A_F4 + B_F4 : 0) + (NKK / 2) * (MI + NI);
+      constexpr int per = n_mfma / (n_mem > 0 ? n_mem : 1) > 0 ? n_mfma / (n_mem > 0 ? n_mem : 1) : 1;
+      // order: first fragment prefetch, LDS writes of tile kt+1, remaining fragment prefetches, then the global
+      // loads of tile kt+2 last - so the lgkmcnt(0) in front of the barrier only waits on long-finished LDS ops
+#pragma unroll
+      for (int i = 0; i < MI + NI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (HAS1) {
+#pragma unroll
+        for (int i = 0; i < A_F4 + B_F4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < (NKK / 2 - 1) * (MI + NI); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (HAS2) {
+#pragma unroll
+        for (int i = 0; i < A_F4 + B_F4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+    }
+    __syncthreads();  // tile kt+1 is now visible to every wave
+    // ---- second half: k-groups NKK/2 .. NKK-1; the last one prefetches the next tile's first k-group
+#pragma unroll
+    for (int kk = NKK / 2; kk < NKK; ++kk) {
+      if (kk + 1 < NKK) {
+        if (kk & 1) { IKF_FRAG(fa0, fb0, cur, kk + 1) } else { IKF_FRAG(fa1, fb1, cur, kk + 1) }
+      } else if (HAS1) {
+        IKF_FRAG(fa0, fb0, nxt, 0)
+      }
+      if (kk & 1) { IKF_MFMA4(fa1, fb1) } else { IKF_MFMA4(fa0, fb0) }
+    }
+    {
+      constexpr int n_mfma = (NKK - NKK / 2) * MI * NI * 4;
+      constexpr int n_rd = ((NKK - NKK / 2 - 1) + (HAS1 ? 1 : 0)) * (MI + NI);
+      constexpr int per = n_rd > 0 ? (n_mfma / n_rd > 0 ? n_mfma / n_rd : 1) : n_mfma;
+#pragma unroll
+      for (int i = 0; i < n_rd; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  // prologue: tile 0 -> stage 0, tile 1 -> registers
+  IKF_GLOAD(0)
+  IKF_LSTORE(0)
+  if (KT > 1) IKF_GLOAD(BK)
+  __syncthreads();
+  IKF_FRAG(fa0, fb0, 0, 0)
+
+  int cur = 0, kt = 0;
+  for (; kt + 2 < KT; ++kt) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, T_{}, kt, cur, nxt);
+    cur = nxt;
+  }
+  if (kt + 1 < KT) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, F_{}, kt, cur, nxt);
+    cur = nxt;
+    ++kt;
+  }
+  k_tile(F_{}, F_{}, kt, cur, cur);
+#undef IKF_GLOAD
+#undef IKF_LSTORE
+#undef IKF_FRAG
+#undef IKF_MFMA4
+
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int col = n0 + wn + j * 32 + col_l;
+    const float bv = bias[col];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        float v = acc[i][j][r] + bv;
+        v = v > 0.f ? v : v * slope;
+        C[(size_t)row * N + col] = v;  // C has its rows padded to a multiple of BM (engine scratch): no predicate
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+static hipError_t launch_gemm_p3(const float* A, const float* W, const float* bias, float* C, long long M, int N, int K,
+                                 float slope, hipStream_t s) {
+  if (N % BN != 0 || K % BK != 0) return hipErrorInvalidValue;
+  constexpr int LDK = BK + 4;
+  constexpr size_t smem = (size_t)3 * (BM + BN) * LDK * sizeof(float);
+  auto kern = k_gemm_lrelu_p3<BM, BN, BK, WAVES_M, WAVES_N>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long long tiles_m = (M + BM - 1) / BM;
+  const long long grid = tiles_m * (N / BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), smem, s, A, W, bias, C, (int)M, N, K,
+                     slope);
+  return hipGetLastError();
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -262,7 +500,7 @@ static hipError_t launch_gemm_t(const float* A, const float* W, const float* bia
   return hipGetLastError();
 }
 
-int gemm_variant_count() { return 6; }
+int gemm_variant_count() { return 9; }
 const char* gemm_kernel_name() { return "k_gemm_lrelu"; }
 
 hipError_t launch_gemm_lrelu(int variant, const float* A, const float* W, const float* bias, float* C, long long M,
@@ -281,6 +519,12 @@ hipError_t launch_gemm_lrelu(int variant, const float* A, const float* W, const 
       return launch_gemm_t<64, 64, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
     case 5:  // 64x128
       return launch_gemm_t<64, 128, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    case 6:  // pipelined 128x128, 4 waves
+      return launch_gemm_p3<128, 128, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
+    case 7:  // pipelined 128x128, 8 waves
+      return launch_gemm_p3<128, 128, 32, 2, 4>(A, W, bias, C, M, N, K, slope, s);
+    case 8:  // pipelined 128x64 (two workgroups per CU)
+      return launch_gemm_p3<128, 64, 32, 2, 2>(A, W, bias, C, M, N, K, slope, s);
     default:
       return hipErrorInvalidValue;
   }

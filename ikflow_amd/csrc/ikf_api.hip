@@ -321,7 +321,7 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
 // ---------------------------------------------------------------------------------------------------------------
 static ikf_status ensure_scratch(ikf_model* m, long long rows) {
   long long want = rows < kMaxChunkRows ? rows : kMaxChunkRows;
-  if (want < 128) want = 128;
+  want = (want + 127) / 128 * 128;  // the contraction kernels store whole 128-row tiles (no row predicate)
   if (want <= m->chunk_rows) return IKF_OK;
   free_scratch(m);
   IKF_HIP(hipMalloc(&m->xbuf, sizeof(float) * (size_t)want * m->dims.D));

@@ -1,0 +1,91 @@
+// Standalone probe for the dominant kernel: times every k_gemm_lrelu variant with hipEvents on random data and checks
+// each against a naive fp32 reference.  Build & run:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_probe.hip
+//   -o gpurun_out/gemm_probe && gpurun_out/gemm_probe [M] [iters]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "../ikflow_amd/csrc/flow_kernels.hip"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+__global__ void k_ref(const float* A, const float* W, const float* bias, float* C, int M, int N, int K, float slope) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+  if (n >= N || m >= M) return;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(A[(size_t)m * K + k], W[(size_t)n * K + k], acc);
+  acc += bias[n];
+  C[(size_t)m * N + n] = acc > 0.f ? acc : acc * slope;
+}
+
+// pure MFMA stream: 4 independent accumulators, n_mfma instructions per wave, no memory traffic - the matrix-pipe
+// ceiling at the clock the chip actually sustains
+__global__ __launch_bounds__(512) void k_mfma_only(float* out, int n_mfma, float a, float b) {
+  ikf::floatx16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float av = a + threadIdx.x * 1e-6f, bv = b;
+  for (int i = 0; i < n_mfma / 4; ++i) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[3], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
+int main(int argc, char** argv) {
+  int M = argc > 1 ? atoi(argv[1]) : 4096;
+  int iters = argc > 2 ? atoi(argv[2]) : 100;
+  const int N = 1024, K = 1024;
+  const int Mp = (M + 127) / 128 * 128;
+  std::vector<float> hA((size_t)Mp * K), hW((size_t)N * K), hb(N);
+  srand(1);
+  for (auto& v : hA) v = (rand() / (float)RAND_MAX) * 2.f - 1.f;
+  for (auto& v : hW) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.03125f;
+  for (auto& v : hb) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.03125f;
+  float *A, *W, *b, *C, *R;
+  CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&b, N * 4));
+  CK(hipMalloc(&C, (size_t)Mp * N * 4)); CK(hipMalloc(&R, (size_t)Mp * N * 4));
+  CK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b, hb.data(), N * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ref, dim3(N / 256, M), dim3(256), 0, 0, A, W, b, R, M, N, K, 0.01f);
+  CK(hipDeviceSynchronize());
+  std::vector<float> hR((size_t)M * N), hC((size_t)M * N);
+  CK(hipMemcpy(hR.data(), R, hR.size() * 4, hipMemcpyDeviceToHost));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const double flop = 2.0 * M * N * K;
+  for (int waves = 4; waves <= 8; waves += 4) {
+    const int n_mfma = 2048 * 4 / waves;  // same total MFMA work per CU as one 128x128x1024 tile
+    for (int rep = 0; rep < 2; ++rep) {
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_mfma_only, dim3(256), dim3(waves * 64), 0, 0, C, n_mfma, 0.5f, 0.25f);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_mfma_only, dim3(256), dim3(waves * 64), 0, 0, C, n_mfma, 0.5f, 0.25f);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("mfma-only %d waves/CU: %.2f us/launch  %.1f TFLOP/s-equivalent\n", waves, 1000.0 * ms / iters, flop / (ms / iters * 1e-3) / 1e12);
+    }
+  }
+  int vsel = argc > 3 ? atoi(argv[3]) : -1;
+  for (int v = 0; v < ikf::gemm_variant_count(); ++v) {
+    if (vsel >= 0 && v != vsel) continue;
+    CK(hipMemset(C, 0, (size_t)Mp * N * 4));
+    hipError_t e = ikf::launch_gemm_lrelu(v, A, W, b, C, M, N, K, 0.01f, 0);
+    if (e != hipSuccess) { printf("variant %d: launch error %s\n", v, hipGetErrorString(e)); continue; }
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0; 
+    for (size_t i = 0; i < hC.size(); ++i) maxerr = fmax(maxerr, fabs((double)hC[i] - hR[i]));
+    for (int rep = 0; rep < 3; ++rep) {
+      for (int i = 0; i < 10; ++i) ikf::launch_gemm_lrelu(v, A, W, b, C, M, N, K, 0.01f, 0);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) ikf::launch_gemm_lrelu(v, A, W, b, C, M, N, K, 0.01f, 0);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("variant %d M=%d: %.2f us/launch  %.1f TFLOP/s  maxerr %.2e\n", v, M, 1000.0 * ms / iters, flop / (ms / iters * 1e-3) / 1e12, maxerr);
+    }
+  }
+  return 0;
+}
