@@ -11,7 +11,7 @@ remote URL and there is no network.  With N > 1 every rank processes its own 409
 step ends with the one RCCL all-gather of the [4096 x 7] solutions.
 
 Rank 0 prints ONE JSON line: metric/value/unit per BASELINE.json, plus `roofline` for the dominant kernel
-(k_gemm_lrelu: the [B x 1024].[1024 x 1024]^T fp32-MFMA contraction) and `cpu_baseline` (the torch-CPU oracle timed on
+(k_flow_gemm: the [B x 1024].[1024 x 1024]^T fp32-MFMA contraction) and `cpu_baseline` (the torch-CPU oracle timed on
 this host's cores on a bounded sample; N=1 only).
 """
 import argparse
@@ -133,8 +133,13 @@ def main():
         elapsed = float(t.item())
     assert bool(torch.isfinite(sol).all())
 
-    # dominant kernel: HIP-event timing of back-to-back launches on the engine's stream, same shapes/data as above
-    gemm_ms = eng.time_gemm(B, 200)
+    # dominant kernel: per-launch HIP-event timing (on the engine's stream) of every hidden-Linear contraction inside
+    # a few more, otherwise identical, steps
+    eng.profile_begin()
+    for _ in range(min(10, max(2, args.steps))):
+        step()
+    n_launch, tot_ms = eng.profile_end()
+    gemm_ms = tot_ms / max(n_launch, 1)
     flop_per_launch = 2.0 * B * layout.width * layout.width
     achieved = flop_per_launch / (gemm_ms * 1e-3) / 1e12
     value = world * B * args.steps / elapsed

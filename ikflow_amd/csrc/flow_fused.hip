@@ -1,0 +1,485 @@
+// Three kernels per coupling subnet (gfx950).  The subnet  Linear(in,W)-LReLU-[Linear(W,W)-LReLU]x-Linear(W,2L) + affine
+// coupling (FrEIA GLOWCouplingBlock rev, call site ikflow/ikflow_solver.py:98, subnet ikflow/model.py:51-96) runs as
+//
+//   k_subnet_entry        finish the PREVIOUS subnet (sum its last-Linear partials, s = clamp*0.636*atan(s),
+//                         y = (x - t)*exp(-s), PermuteRandom^-1), publish the new flow state, assemble u = [x_part, pose]
+//                         in LDS and evaluate the first Linear + LReLU -> h1            (VALU; HBM/L3 write bound)
+//   k_flow_gemm<false>    hidden Linear + LReLU,  h -> h                               (f32 MFMA bound)
+//   k_flow_gemm<true>     last hidden Linear + LReLU kept on chip (LDS), then the last Linear restricted to this tile's
+//                         columns as a second small MFMA contraction -> partial sums P[slot][row][o]; the hidden
+//                         activation of the last layer never goes to HBM
+//   k_flow_finalize       after the last subnet: "finish the previous subnet" + FixedLinearTransform^-1, [:, :ndof],
+//                         clamp_to_joint_limits (ikflow_solver.py:99-102)
+//
+// The K loop is the 3-stage / one-barrier-per-tile pipeline of k_gemm_lrelu_p3 (flow_kernels.hip), 8 waves of 64x32.
+// (Generating the A operand of the first hidden contraction on the fly was measured and rejected: its ~110 VALU
+// instructions per wave per K tile did not stay in the MFMA shadow - 98 us against 65 us + a 5 us entry kernel.)
+#include <type_traits>
+
+#include "ikf_internal.h"
+
+namespace ikf {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int FBM = 128, FBN = 128, FBK = 32, FWAVES_M = 2, FWAVES_N = 4;  // 8 waves of 64x32
+constexpr int FNT = FWAVES_M * FWAVES_N * 64;
+constexpr int FKH = (FNT / 64) / (FBM / 32);  // column splits of the partial-sum epilogue (= slots per tile)
+constexpr int ROWBUF = 16;                    // floats per row in the small per-row LDS arrays (>= D, >= n_out)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Finish a pending coupling for R rows starting at m0 and leave the new state rows in LDS sn[R][ROWBUF].
+// aa, so, sn: LDS arrays of R*ROWBUF floats.  All NT threads participate; ends with a barrier.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, int R>
+__device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const float* __restrict__ x_src,
+                                                    int D, int L1, float clamp, int m0, int M, float* aa, float* so,
+                                                    float* sn, int t) {
+  const int L2 = D - L1;
+  for (int idx = t; idx < R * D; idx += NT) {
+    const int r = idx / D, d = idx - r * D;
+    int gr = m0 + r;
+    gr = gr < M ? gr : M - 1;
+    so[r * ROWBUF + d] = x_src[(size_t)gr * D + d];
+  }
+  if (pc.P != nullptr) {
+    for (int idx = t; idx < R * pc.n_out; idx += NT) {
+      const int r = idx / pc.n_out, j = idx - r * pc.n_out;
+      const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + j;  // P rows are padded to the tile: no clamp needed
+      float a = pc.b_last[j];
+      for (int s0 = 0; s0 < pc.slots; s0 += 16) {  // 16 independent loads in flight, then a fixed-order sum
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (s0 + q < pc.slots) ? p[(size_t)(s0 + q) * pc.slot_stride] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a += v[q];
+      }
+      aa[r * ROWBUF + j] = a;
+    }
+  }
+  __syncthreads();
+  if (pc.P == nullptr) {
+    for (int idx = t; idx < R * D; idx += NT) {
+      const int r = idx / D, d = idx - r * D;
+      sn[r * ROWBUF + d] = so[r * ROWBUF + d];
+    }
+    __syncthreads();
+    return;
+  }
+  // which == 1: y2 = (x2 - t1) * exp(-s1), x1 untouched.   which == 2: y1 = (x1 - t2) * exp(-s2), then perm_inv gather
+  const int nl = (pc.which == 1) ? L2 : L1;
+  const int off = (pc.which == 1) ? L1 : 0;
+  for (int idx = t; idx < R * D; idx += NT) {
+    const int r = idx / D, d = idx - r * D;
+    float v = so[r * ROWBUF + d];
+    if (d >= off && d < off + nl) {
+      const int j = d - off;
+      const float sv = aa[r * ROWBUF + j], tv = aa[r * ROWBUF + nl + j];
+      const float s_cl = clamp * (0.636f * atanf(sv));
+      v = (v - tv) * expf(-s_cl);
+    }
+    sn[r * ROWBUF + d] = v;
+  }
+  __syncthreads();
+  if (pc.which == 2) {
+    // PermuteRandom rev: out[:, d] = cat[:, perm_inv[d]]  (ikflow/model.py:339)
+    for (int idx = t; idx < R * D; idx += NT) {
+      const int r = idx / D, d = idx - r * D;
+      so[r * ROWBUF + d] = sn[r * ROWBUF + pc.perm_inv[d]];
+    }
+    __syncthreads();
+    for (int idx = t; idx < R * D; idx += NT) {
+      const int r = idx / D, d = idx - r * D;
+      sn[r * ROWBUF + d] = so[r * ROWBUF + d];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// subnet entry: pending coupling + first Linear + LeakyReLU for ER rows per workgroup
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ER = 16;
+
+template <int IN>
+__global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
+  constexpr int NT = 256;
+  __shared__ __attribute__((aligned(16))) float aa[ER * ROWBUF], so[ER * ROWBUF], sn[ER * ROWBUF], U[ER * ROWBUF];
+  const int t = threadIdx.x;
+  const int m0 = blockIdx.x * ER;
+  const int M = e.M, D = e.D;
+  finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, aa, so, sn, t);
+  for (int idx = t; idx < ER * D; idx += NT) {
+    const int r = idx / D, d = idx - r * D;
+    if (m0 + r < M) e.x_dst[(size_t)(m0 + r) * D + d] = sn[r * ROWBUF + d];
+  }
+  for (int idx = t; idx < ER * IN; idx += NT) {
+    const int r = idx / IN, k = idx - r * IN;
+    float v;
+    if (k < e.n_x) {
+      v = sn[r * ROWBUF + e.x_off + k];
+    } else {
+      int gr = m0 + r;
+      gr = gr < M ? gr : M - 1;
+      const long long grow = e.row0 + gr;
+      const long long pm = grow % e.ps.n_mod;
+      const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
+      v = e.ps.poses[pi * e.ps.stride + (k - e.n_x)];
+    }
+    U[r * ROWBUF + k] = v;
+  }
+  __syncthreads();
+  const int n4 = e.width >> 2;
+  for (int c4 = t; c4 < n4; c4 += NT) {
+    floatx4 w[IN];
+#pragma unroll
+    for (int k = 0; k < IN; ++k) w[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
+    floatx4 b = reinterpret_cast<const floatx4*>(e.b1)[c4];
+    if (e.ps.softflow != 0.0f) b += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft)[c4];
+#pragma unroll 4
+    for (int r = 0; r < ER; ++r) {
+      floatx4 acc = b;
+#pragma unroll
+      for (int k = 0; k < IN; ++k) {
+        const float u = U[r * ROWBUF + k];  // same address in every lane: LDS broadcast
+        acc.x = fmaf(u, w[k].x, acc.x);
+        acc.y = fmaf(u, w[k].y, acc.y);
+        acc.z = fmaf(u, w[k].z, acc.z);
+        acc.w = fmaf(u, w[k].w, acc.w);
+      }
+      acc.x = acc.x > 0.f ? acc.x : acc.x * e.slope;
+      acc.y = acc.y > 0.f ? acc.y : acc.y * e.slope;
+      acc.z = acc.z > 0.f ? acc.z : acc.z * e.slope;
+      acc.w = acc.w > 0.f ? acc.w : acc.w * e.slope;
+      // h rows are padded to a multiple of 128 (engine scratch): unpredicated
+      reinterpret_cast<floatx4*>(e.h_out + (size_t)(m0 + r) * e.width)[c4] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// hidden contraction; EPI_RED: reduce the last Linear in the epilogue instead of storing the activation
+// ---------------------------------------------------------------------------------------------------------------
+template <bool EPI_RED>
+__global__ __launch_bounds__(FNT) void k_flow_gemm(FusedGemmArgs g) {
+  constexpr int BM = FBM, BN = FBN, BK = FBK, NT = FNT;
+  constexpr int WM = BM / FWAVES_M, WN = BN / FWAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int LDK = BK + 4;
+  constexpr int KQ = BK / 4;
+  constexpr int A_F4 = BM * KQ / NT;
+  constexpr int B_F4 = BN * KQ / NT;
+  constexpr int RS = NT / KQ;
+  constexpr int NKK = BK / 8;
+  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int LDT = BN + 4;  // epilogue tile row stride
+  static_assert(BM * KQ % NT == 0 && BN * KQ % NT == 0 && NT % KQ == 0, "tile/threads mismatch");
+  static_assert(NKK % 2 == 0 && NKK >= 2, "fragment double-buffering needs an even number of k-groups");
+  static_assert(3 * STAGE >= (BM + 32) * LDT, "epilogue tile must fit in the stage area");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][LDK]
+
+  const int M = g.M, N = g.N, K = g.K;
+  const int tiles_n = N / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = (wave / FWAVES_N) * WM, wn = (wave % FWAVES_N) * WN;
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int row_t = t / KQ, kq_t = (t % KQ) * 4;
+  const float* a_src[A_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    int gr = m0 + row_t + i * RS;
+    gr = gr < M ? gr : M - 1;
+    a_src[i] = g.A + (size_t)gr * K + kq_t;
+  }
+  const float* b_base = g.W + (size_t)(n0 + row_t) * K + kq_t;
+  const int lds_t = row_t * LDK + kq_t;
+  const int fragA = (wm + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int fragB = BM * LDK + (wn + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int KT = K / BK;
+
+  floatx4 ra[A_F4], rb[B_F4];
+  floatx4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
+
+#define IKF_GLOAD(koff)                                                                                           \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const floatx4*>(a_src[i] + (koff)); \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
+        rb[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (koff));                        \
+  }
+#define IKF_LSTORE(stage)                                                                                         \
+  {                                                                                                               \
+    float* sp_ = smem + (stage) * STAGE + lds_t;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp_ + i * RS * LDK) = ra[i];      \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
+        *reinterpret_cast<floatx4*>(sp_ + BM * LDK + i * RS * LDK) = rb[i];                                       \
+  }
+#define IKF_FRAG(FA, FB, stage, kk)                                                                               \
+  {                                                                                                               \
+    const float* sp_ = smem + (stage) * STAGE + (kk) * 8;                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = *reinterpret_cast<const floatx4*>(sp_ + fragA + i * 32 * LDK); \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = *reinterpret_cast<const floatx4*>(sp_ + fragB + j * 32 * LDK); \
+  }
+#define IKF_MFMA4(FA, FB)                                                                                         \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].x, FB[j].x, acc[i][j], 0, 0, 0);                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].y, FB[j].y, acc[i][j], 0, 0, 0);                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].z, FB[j].z, acc[i][j], 0, 0, 0);                     \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i].w, FB[j].w, acc[i][j], 0, 0, 0);                     \
+    }                                                                                                             \
+  }
+
+  // One K tile; HAS1/HAS2 (tile kt+1 / kt+2 exist) are compile-time so the steady-state body is branch-free and the
+  // sched_group_barrier sequences pin a k-MFMA : 1-memory-op interleave on both sides of the barrier.
+  auto k_tile = [&](auto has1_c, auto has2_c, int kt, int cur, int nxt) {
+    constexpr bool HAS1 = decltype(has1_c)::value, HAS2 = decltype(has2_c)::value;
+#pragma unroll
+    for (int kk = 0; kk < NKK / 2; ++kk) {
+      if (kk & 1) { IKF_FRAG(fa0, fb0, cur, kk + 1) } else { IKF_FRAG(fa1, fb1, cur, kk + 1) }
+      if (kk & 1) { IKF_MFMA4(fa1, fb1) } else { IKF_MFMA4(fa0, fb0) }
+      if (kk == 0) {
+        if (HAS1) IKF_LSTORE(nxt)
+        if (HAS2) IKF_GLOAD((kt + 2) * BK)
+      }
+    }
+    {
+      constexpr int n_mfma = (NKK / 2) * MI * NI * 4;
+      constexpr int n_mem = (HAS1 ? A_F4 + B_F4 : 0) + (HAS2 ? A_F4 + B_F4 : 0) + (NKK / 2) * (MI + NI);
+      constexpr int per = n_mfma / (n_mem > 0 ? n_mem : 1) > 0 ? n_mfma / (n_mem > 0 ? n_mem : 1) : 1;
+#pragma unroll
+      for (int i = 0; i < MI + NI; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (HAS1) {
+#pragma unroll
+        for (int i = 0; i < A_F4 + B_F4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < (NKK / 2 - 1) * (MI + NI); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (HAS2) {
+#pragma unroll
+        for (int i = 0; i < A_F4 + B_F4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = NKK / 2; kk < NKK; ++kk) {
+      if (kk + 1 < NKK) {
+        if (kk & 1) { IKF_FRAG(fa0, fb0, cur, kk + 1) } else { IKF_FRAG(fa1, fb1, cur, kk + 1) }
+      } else if (HAS1) {
+        IKF_FRAG(fa0, fb0, nxt, 0)
+      }
+      if (kk & 1) { IKF_MFMA4(fa1, fb1) } else { IKF_MFMA4(fa0, fb0) }
+    }
+    {
+      constexpr int n_mfma = (NKK - NKK / 2) * MI * NI * 4;
+      constexpr int n_rd = ((NKK - NKK / 2 - 1) + (HAS1 ? 1 : 0)) * (MI + NI);
+      constexpr int per = n_rd > 0 ? (n_mfma / n_rd > 0 ? n_mfma / n_rd : 1) : n_mfma;
+#pragma unroll
+      for (int i = 0; i < n_rd; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, per, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  IKF_GLOAD(0)
+  IKF_LSTORE(0)
+  if (KT > 1) IKF_GLOAD(BK)
+  __syncthreads();
+  IKF_FRAG(fa0, fb0, 0, 0)
+
+  int cur = 0, kt = 0;
+  for (; kt + 2 < KT; ++kt) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, T_{}, kt, cur, nxt);
+    cur = nxt;
+  }
+  if (kt + 1 < KT) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, F_{}, kt, cur, nxt);
+    cur = nxt;
+    ++kt;
+  }
+  k_tile(F_{}, F_{}, kt, cur, cur);
+#undef IKF_GLOAD
+#undef IKF_LSTORE
+#undef IKF_FRAG
+#undef IKF_MFMA4
+
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  if constexpr (!EPI_RED) {
+    // bias + LeakyReLU, unpredicated stores into the row-padded activation buffer
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int col = n0 + wn + j * 32 + col_l;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          float v = acc[i][j][r] + bv;
+          v = v > 0.f ? v : v * g.slope;
+          g.C[(size_t)row * N + col] = v;
+        }
+      }
+    }
+  } else {
+    // ---- last Linear restricted to this tile's columns:  P^T[o][row] = sum_col W4[o][col] * h[row][col]
+    // h tile -> LDS T[BM][LDT]; W4 slice -> LDS Wl[32][LDT] (rows >= n_out zero); then the same K-contiguous fragment
+    // scheme as the main loop with "A" = Wl (32 x BN) and "B" = T (BM x BN): wave w owns row block w % 4 and the
+    // column half w / 4 (its own partial-sum slot).
+    __syncthreads();  // every wave is done reading the last stage
+    float* T = smem;
+    float* Wl = smem + BM * LDT;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int cl = wn + j * 32 + col_l;
+      const float bv = g.bias[n0 + cl];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+          float v = acc[i][j][r] + bv;
+          v = v > 0.f ? v : v * g.slope;
+          T[rl * LDT + cl] = v;
+        }
+      }
+    }
+    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
+      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
+    }
+    __syncthreads();
+    constexpr int RB = BM / 32;
+    constexpr int CW = BN / FKH;  // columns per split
+    const int rb = wave % RB, kh = wave / RB;
+    floatx16 pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+    const float* pa = Wl + (lane & 31) * LDT + kh * CW + (lane >> 5) * 4;
+    const float* pb = T + (rb * 32 + (lane & 31)) * LDT + kh * CW + (lane >> 5) * 4;
+#pragma unroll
+    for (int ks = 0; ks < CW / 8; ++ks) {
+      const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
+      const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
+      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+    }
+    // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7
+    float* pout = g.P_out + (size_t)(tn * FKH + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int o = (r & 3) + 8 * (r >> 2) + row_h;
+      pout[o] = pacc[r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
+  constexpr int R = 128, NT = 256;
+  __shared__ float aa[R * ROWBUF], so[R * ROWBUF], sn[R * ROWBUF];
+  const int t = threadIdx.x;
+  const int m0 = blockIdx.x * R;
+  finish_pending_rows<NT, R>(f.pend, f.x_src, f.D, f.L1, f.clamp, m0, f.M, aa, so, sn, t);
+  // FixedLinearTransform rev: (x - b).mm(M_inv); [:, :ndof]; clamp_to_joint_limits
+  const int D = f.D;
+  for (int idx = t; idx < R * f.ndof; idx += NT) {
+    const int r = idx / f.ndof, j = idx - r * f.ndof;
+    if (m0 + r >= f.M) continue;
+    float q = 0.f;
+    for (int k = 0; k < D; ++k) q = fmaf(sn[r * ROWBUF + k] - f.b_lin[k], f.M_inv[k * D + j], q);
+    if (f.clamp_limits) q = fminf(fmaxf(q, f.lo[j]), f.hi[j]);
+    f.q_out[(size_t)(m0 + r) * f.ndof + j] = q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int fused_slots_per_tile() { return FKH; }
+int fused_tile_n() { return FBN; }
+const char* fused_kernel_name() { return "k_flow_gemm"; }
+
+template <bool EPI_RED>
+static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)3 * (FBM + FBN) * (FBK + 4) * sizeof(float);
+  auto kern = k_flow_gemm<EPI_RED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long long tiles_m = ((long long)a.M + FBM - 1) / FBM;
+  const long long grid = tiles_m * (a.N / FBN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FNT), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_flow_gemm(bool epi_red, const FusedGemmArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.N % FBN != 0 || a.K % FBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
+  return epi_red ? launch_fg<true>(a, s) : launch_fg<false>(a, s);
+}
+
+hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s) {
+  if (e.M <= 0) return hipSuccess;
+  if (e.D > ROWBUF || e.pend.n_out > ROWBUF || e.width % 4 != 0) return hipErrorInvalidValue;
+  const unsigned grid = (unsigned)((e.M + ER - 1) / ER);
+#define IKF_ENTRY_CASE(IN) \
+  case IN: hipLaunchKernelGGL((k_subnet_entry<IN>), dim3(grid), dim3(256), 0, s, e); break;
+  switch (n_in) {
+    IKF_ENTRY_CASE(8) IKF_ENTRY_CASE(9) IKF_ENTRY_CASE(10) IKF_ENTRY_CASE(11)
+    IKF_ENTRY_CASE(12) IKF_ENTRY_CASE(13) IKF_ENTRY_CASE(14) IKF_ENTRY_CASE(15)
+    default: return hipErrorInvalidValue;
+  }
+#undef IKF_ENTRY_CASE
+  return hipGetLastError();
+}
+
+hipError_t launch_flow_finalize(const FinalizeArgs& f, hipStream_t s) {
+  if (f.M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_flow_finalize, dim3((unsigned)((f.M + 127) / 128)), dim3(256), 0, s, f);
+  return hipGetLastError();
+}
+
+}  // namespace ikf

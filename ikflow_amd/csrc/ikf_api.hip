@@ -45,6 +45,8 @@ struct ikf_model {
   // scratch
   long long chunk_rows = 0;  // capacity of the per-chunk flow scratch
   float* xbuf = nullptr;     // [chunk][D]
+  float* xbuf2 = nullptr;    // [chunk][D]   second state buffer (fused path ping-pongs the state)
+  float* pbuf = nullptr;     // [slots][chunk][IKF_PSTRIDE] last-Linear partial sums (fused path)
   float* hA = nullptr;       // [chunk][width]
   float* hB = nullptr;
   // exact-IK scratch
@@ -55,19 +57,38 @@ struct ikf_model {
   uint8_t* ex_solved = nullptr;   // [poses]
   int* ex_count = nullptr;        // device
   int* h_count = nullptr;         // pinned host
+
+  // optional per-launch HIP-event timing of the dominant kernel (ikf_profile_begin/_end)
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;  // pairs
+  size_t prof_used = 0;
 };
+
+static const size_t kProfMaxPairs = 8192;
+static hipError_t prof_mark(ikf_model* m, hipStream_t s) {
+  if (!m->prof_on || m->prof_used >= 2 * kProfMaxPairs) return hipSuccess;
+  if (m->prof_used >= m->prof_ev.size()) {
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return r;
+    m->prof_ev.push_back(e);
+  }
+  return hipEventRecord(m->prof_ev[m->prof_used++], s);
+}
 
 static const long long kMaxChunkRows = 16384;  // keeps the [chunk x width] activations (64 MB each) inside the 256 MB L3
 
 extern "C" const char* ikf_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ikf_abi_version(void) { return IKF_ABI_VERSION; }
-extern "C" const char* ikf_dominant_kernel_name(void) { return gemm_kernel_name(); }
+extern "C" const char* ikf_dominant_kernel_name(void) { return fused_kernel_name(); }
 
 static void free_scratch(ikf_model* m) {
   if (m->xbuf) (void)hipFree(m->xbuf);
   if (m->hA) (void)hipFree(m->hA);
   if (m->hB) (void)hipFree(m->hB);
-  m->xbuf = m->hA = m->hB = nullptr;
+  if (m->xbuf2) (void)hipFree(m->xbuf2);
+  if (m->pbuf) (void)hipFree(m->pbuf);
+  m->xbuf = m->hA = m->hB = m->xbuf2 = m->pbuf = nullptr;
   m->chunk_rows = 0;
 }
 static void free_exact(ikf_model* m) {
@@ -148,6 +169,7 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->d_chain) (void)hipFree(m->d_chain);
   if (m->ex_count) (void)hipFree(m->ex_count);
   if (m->h_count) (void)hipHostFree(m->h_count);
+  for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   delete m;
 }
 
@@ -327,6 +349,9 @@ static ikf_status ensure_scratch(ikf_model* m, long long rows) {
   IKF_HIP(hipMalloc(&m->xbuf, sizeof(float) * (size_t)want * m->dims.D));
   IKF_HIP(hipMalloc(&m->hA, sizeof(float) * (size_t)want * m->dims.width));
   IKF_HIP(hipMalloc(&m->hB, sizeof(float) * (size_t)want * m->dims.width));
+  IKF_HIP(hipMalloc(&m->xbuf2, sizeof(float) * (size_t)want * m->dims.D));
+  const size_t slots = (size_t)(m->dims.width / fused_tile_n()) * fused_slots_per_tile();
+  IKF_HIP(hipMalloc(&m->pbuf, sizeof(float) * slots * (size_t)want * IKF_PSTRIDE));
   m->chunk_rows = want;
   return IKF_OK;
 }
@@ -355,7 +380,8 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
 
 extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
-  if (variant < -1 || variant >= gemm_variant_count()) return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant");
+  if (variant != 100 && (variant < -1 || variant >= gemm_variant_count()))
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused)");
   m->gemm_variant = variant;
   return IKF_OK;
 }
@@ -374,42 +400,123 @@ static int pick_variant(const ikf_model* m, long long rows) {
 // ---------------------------------------------------------------------------------------------------------------
 // flow inverse pass over `rows` rows (chunked); replaces nn_model(latent, c=cond, rev=True) + slice + clamp
 // ---------------------------------------------------------------------------------------------------------------
+static const float* chain_lo(const ikf_model* m) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, lo));
+}
+static const float* chain_hi(const ikf_model* m) {
+  return reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, hi));
+}
+
+static bool fused_ok(const ikf_model* m) {
+  const FlowDims& d = m->dims;
+  if (m->gemm_variant >= 0 && m->gemm_variant != 100) return false;
+  return d.n_hidden >= 2 && d.width % fused_tile_n() == 0 && d.D <= 16 && 2 * d.L2 <= 16 &&
+         d.L1 + d.n_pose >= 8 && d.L2 + d.n_pose <= 15;
+}
+
+// three kernels per subnet (flow_fused.hip): entry (pending coupling + first Linear), hidden contraction(s), the last
+// of which reduces the last Linear to partial sums; one finalize kernel after the last subnet
+static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r0,
+                                       long long nr, int clamp_limits, float* d_q_out, hipStream_t s) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes;
+  const long long rows_pad = m->chunk_rows;
+  const int slots = (d.width / fused_tile_n()) * fused_slots_per_tile();
+  PendingCoupling pend{};
+  pend.P = nullptr;
+  const float* x_src = d_latent + (size_t)r0 * d.D;
+  float* xb[2] = {m->xbuf, m->xbuf2};
+  for (int sidx = 0; sidx < 2 * NB; ++sidx) {
+    const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
+    const SubnetWeights& w = m->subnets[2 * b + which - 1];
+    EntryArgs e{};
+    e.pend = pend;
+    e.x_src = x_src; e.x_dst = xb[sidx & 1];
+    e.M = (int)nr; e.D = d.D; e.L1 = d.L1; e.clamp = d.clamp;
+    e.x_off = (which == 1) ? 0 : d.L1; e.n_x = w.n_x;
+    e.ps = ps; e.row0 = r0;
+    e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
+    e.width = d.width; e.slope = d.slope; e.h_out = m->hA;
+    IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
+    FusedGemmArgs g{};
+    g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
+    g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
+    const int n_mid = d.n_hidden - 1;
+    float* cur = m->hA;
+    float* nxt = m->hB;
+    for (int l = 0; l < n_mid; ++l) {
+      const bool last = (l == n_mid - 1);
+      g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
+      IKF_HIP(prof_mark(m, s));
+      IKF_HIP(launch_flow_gemm(last, g, s));
+      IKF_HIP(prof_mark(m, s));
+      float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    pend.P = m->pbuf;
+    pend.b_last = w.b_last;
+    pend.perm_inv = m->d_perm_inv + (size_t)b * d.D;
+    pend.slot_stride = rows_pad * IKF_PSTRIDE;
+    pend.slots = slots;
+    pend.which = which;
+    pend.n_out = w.n_out;
+    x_src = e.x_dst;
+  }
+  FinalizeArgs f{};
+  f.pend = pend; f.x_src = x_src; f.M = (int)nr; f.D = d.D; f.L1 = d.L1; f.ndof = d.ndof; f.clamp = d.clamp;
+  f.M_inv = m->d_Minv; f.b_lin = m->d_blin; f.lo = chain_lo(m); f.hi = chain_hi(m);
+  f.clamp_limits = clamp_limits; f.q_out = d_q_out + (size_t)r0 * d.ndof;
+  IKF_HIP(launch_flow_finalize(f, s));
+  return IKF_OK;
+}
+
+// four-plus kernels per subnet (flow_kernels.hip): first Linear, hidden contractions, last Linear + coupling
+static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r0,
+                                         long long nr, int clamp_limits, float* d_q_out, hipStream_t s) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes;
+  const int variant = pick_variant(m, nr);
+  for (int b = NB - 1; b >= 0; --b) {
+    const float* x_in = (b == NB - 1) ? d_latent + (size_t)r0 * d.D : m->xbuf;
+    for (int which = 1; which <= 2; ++which) {
+      const SubnetWeights& w = m->subnets[2 * b + which - 1];
+      const float* x_src = (which == 1) ? x_in : m->xbuf;
+      IKF_HIP(launch_first_layer(w, d, x_src, which == 1 ? 0 : d.L1, ps, r0, nr, m->hA, s));
+      float* cur = m->hA;
+      float* nxt = m->hB;
+      for (int l = 0; l < d.n_hidden - 1; ++l) {
+        IKF_HIP(prof_mark(m, s));
+        IKF_HIP(launch_gemm_lrelu(variant, cur, w.w_mid[l], w.b_mid[l], nxt, nr, d.width, d.width, d.slope, s));
+        IKF_HIP(prof_mark(m, s));
+        float* tmp = cur; cur = nxt; nxt = tmp;
+      }
+      CouplingArgs ca{};
+      ca.x_in = x_in;
+      ca.x_out = m->xbuf;
+      ca.perm_inv = m->d_perm_inv + (size_t)b * d.D;
+      ca.M_inv = m->d_Minv;
+      ca.b_lin = m->d_blin;
+      ca.lo = chain_lo(m);
+      ca.hi = chain_hi(m);
+      ca.q_out = d_q_out + (size_t)r0 * d.ndof;
+      ca.which = which;
+      ca.is_final = (b == 0 && which == 2) ? 1 : 0;
+      ca.clamp_limits = clamp_limits;
+      IKF_HIP(launch_last_layer_coupling(w, d, cur, ca, nr, s));
+    }
+  }
+  return IKF_OK;
+}
+
 static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
                            float* d_q_out, hipStream_t s) {
   ikf_status st = ensure_scratch(m, rows);
   if (st != IKF_OK) return st;
-  const FlowDims& d = m->dims;
-  const int NB = m->desc.nb_nodes;
+  const bool fused = fused_ok(m);
   for (long long r0 = 0; r0 < rows; r0 += m->chunk_rows) {
     const long long nr = (rows - r0 < m->chunk_rows) ? rows - r0 : m->chunk_rows;
-    const int variant = pick_variant(m, nr);
-    for (int b = NB - 1; b >= 0; --b) {
-      const float* x_in = (b == NB - 1) ? d_latent + (size_t)r0 * d.D : m->xbuf;
-      for (int which = 1; which <= 2; ++which) {
-        const SubnetWeights& w = m->subnets[2 * b + which - 1];
-        const float* x_src = (which == 1) ? x_in : m->xbuf;
-        IKF_HIP(launch_first_layer(w, d, x_src, which == 1 ? 0 : d.L1, ps, r0, nr, m->hA, s));
-        float* cur = m->hA;
-        float* nxt = m->hB;
-        for (int l = 0; l < d.n_hidden - 1; ++l) {
-          IKF_HIP(launch_gemm_lrelu(variant, cur, w.w_mid[l], w.b_mid[l], nxt, nr, d.width, d.width, d.slope, s));
-          float* tmp = cur; cur = nxt; nxt = tmp;
-        }
-        CouplingArgs ca{};
-        ca.x_in = x_in;
-        ca.x_out = m->xbuf;
-        ca.perm_inv = m->d_perm_inv + (size_t)b * d.D;
-        ca.M_inv = m->d_Minv;
-        ca.b_lin = m->d_blin;
-        ca.lo = reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, lo));
-        ca.hi = reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, hi));
-        ca.q_out = d_q_out + (size_t)r0 * d.ndof;
-        ca.which = which;
-        ca.is_final = (b == 0 && which == 2) ? 1 : 0;
-        ca.clamp_limits = clamp_limits;
-        IKF_HIP(launch_last_layer_coupling(w, d, cur, ca, nr, s));
-      }
-    }
+    st = fused ? run_flow_chunk_fused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s)
+               : run_flow_chunk_unfused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s);
+    if (st != IKF_OK) return st;
   }
   return IKF_OK;
 }
@@ -567,14 +674,25 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
   if (rows > m->chunk_rows) rows = m->chunk_rows;
   const SubnetWeights& w = m->subnets[0];
   const int variant = pick_variant(m, rows);
+  const bool fused = fused_ok(m) && m->dims.n_hidden >= 3;
   hipEvent_t e0, e1;
   IKF_HIP(hipEventCreate(&e0));
   IKF_HIP(hipEventCreate(&e1));
-  IKF_HIP(launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width, m->dims.slope, s));
+  FusedGemmArgs g{};
+  if (fused) {
+    // the contraction that reads its A operand from HBM and reduces the last Linear in its epilogue (h -> partials)
+    g.M = (int)rows; g.N = m->dims.width; g.K = m->dims.width; g.slope = m->dims.slope;
+    g.A = m->hA; g.W = w.w_mid[m->dims.n_hidden - 2]; g.bias = w.b_mid[m->dims.n_hidden - 2];
+    g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = m->chunk_rows * IKF_PSTRIDE;
+  }
+  auto launch = [&]() -> hipError_t {
+    if (fused) return launch_flow_gemm(true, g, s);
+    return launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width,
+                             m->dims.slope, s);
+  };
+  IKF_HIP(launch());
   IKF_HIP(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i)
-    IKF_HIP(launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width,
-                              m->dims.slope, s));
+  for (int i = 0; i < iters; ++i) IKF_HIP(launch());
   IKF_HIP(hipEventRecord(e1, s));
   IKF_HIP(hipEventSynchronize(e1));
   float ms = 0.f;
@@ -582,5 +700,30 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *ms_out = ms / iters;
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_profile_begin(ikf_model* m) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_profile_begin: null model");
+  m->prof_on = true;
+  m->prof_used = 0;
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream) {
+  if (!m || !n_launches || !total_ms) return fail(IKF_ERR_NULL_POINTER, "ikf_profile_end: null argument");
+  IKF_HIP(hipSetDevice(m->device));
+  m->prof_on = false;
+  IKF_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  double tot = 0.0;
+  const size_t pairs = m->prof_used / 2;
+  for (size_t i = 0; i < pairs; ++i) {
+    float ms = 0.f;
+    IKF_HIP(hipEventElapsedTime(&ms, m->prof_ev[2 * i], m->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *n_launches = (int64_t)pairs;
+  *total_ms = tot;
+  m->prof_used = 0;
   return IKF_OK;
 }

@@ -61,6 +61,65 @@ hipError_t launch_last_layer_coupling(const SubnetWeights& w, const FlowDims& d,
 int gemm_variant_count();
 const char* gemm_kernel_name();
 
+// flow_fused.hip - the three-kernel-per-subnet form: the last Linear is reduced to per-tile partial sums in the epilogue
+// of the last hidden contraction, and the affine-coupling update runs at the head of the NEXT subnet's entry kernel.
+constexpr int IKF_PSTRIDE = 16;  // floats per row in one partial-sum slot
+struct PendingCoupling {         // coupling of the previous subnet, whose last Linear exists only as partial sums
+  const float* P;                // [slots][rows_pad][IKF_PSTRIDE], or null: no pending (state passes through)
+  const float* b_last;           // [n_out]
+  const int* perm_inv;           // [D], used when which == 2
+  long long slot_stride;         // rows_pad * IKF_PSTRIDE
+  int slots, which, n_out;
+};
+struct EntryArgs {      // k_subnet_entry: pending coupling + first Linear of the next subnet
+  PendingCoupling pend;
+  const float* x_src;   // [M][D] state before the pending coupling
+  float* x_dst;         // [M][D] state after it
+  int M, D, L1;
+  float clamp;
+  int x_off, n_x;       // slice of the new state that feeds this subnet
+  PoseSource ps;
+  long long row0;
+  const float* w1t;     // [IN][width]
+  const float* w1soft;  // [width]
+  const float* b1;      // [width]
+  int width;
+  float slope;
+  float* h_out;         // [rows_pad][width]
+};
+struct FusedGemmArgs {
+  // contraction C = lrelu(A . W^T + bias), K = N = width
+  const float* A;     // [rows_pad][K]
+  const float* W;     // [N][K]
+  const float* bias;  // [N]
+  float* C;           // [rows_pad][N]  (unused when the epilogue reduces to partials)
+  int M, N, K;
+  float slope;
+  // partial-sum epilogue: P_out[slot][row][o] = sum over the tile's columns of lrelu(...)[row][col] * w_last[o][col]
+  const float* w_last;  // [n_out][N]
+  int n_out;
+  float* P_out;         // [slots][rows_pad][IKF_PSTRIDE]
+  long long p_slot_stride;
+};
+struct FinalizeArgs {
+  PendingCoupling pend;
+  const float* x_src;  // [M][D]
+  int M, D, L1, ndof;
+  float clamp;
+  const float* M_inv;  // [D][D]
+  const float* b_lin;  // [D]
+  const float* lo;
+  const float* hi;
+  int clamp_limits;
+  float* q_out;        // [M][ndof]
+};
+int fused_slots_per_tile();  // partial-sum slots one column tile produces
+int fused_tile_n();
+hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s);
+hipError_t launch_flow_gemm(bool epi_red, const FusedGemmArgs& a, hipStream_t s);
+hipError_t launch_flow_finalize(const FinalizeArgs& a, hipStream_t s);
+const char* fused_kernel_name();
+
 // kin_kernels.hip
 struct Chain {
   int ndof;

@@ -300,6 +300,16 @@ class Engine:
             _check(self.lib.ikf_time_gemm(self._h, int(rows), int(iters), C.byref(ms), self._stream()))
         return float(ms.value)
 
+    def profile_begin(self) -> None:
+        _check(self.lib.ikf_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> (number of dominant-kernel launches since profile_begin, sum of their HIP-event durations in ms)"""
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_profile_end(self._h, C.byref(n), C.byref(ms), self._stream()))
+        return int(n.value), float(ms.value)
+
     def dominant_kernel_name(self) -> str:
         return self.lib.ikf_dominant_kernel_name().decode()
 

@@ -142,9 +142,16 @@ ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t
 /* Time `iters` launches of the dominant kernel (the width x width fused Linear+LeakyReLU contraction) on M rows with
  * hipEvents on `stream`; returns average milliseconds per launch in *ms_out. */
 ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float* ms_out, void* stream);
+/* Per-launch timing of the dominant kernel inside real calls: between _begin and _end every hidden-Linear contraction
+ * launched by ikf_generate_approx/_exact on `stream` is bracketed by a hipEvent pair; _end synchronises the stream and
+ * returns the number of launches and the sum of their elapsed times (ms). Adds two event records per launch - use it
+ * on extra steps, not inside a throughput-timed region. */
+ikf_status ikf_profile_begin(ikf_model* m);
+ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
 const char* ikf_dominant_kernel_name(void);
-/* Select the contraction kernel variant (tile shape); 0 = default. Returns IKF_ERR_BAD_ARGUMENT if unknown. */
+/* Select the flow pipeline: -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly,
+ * 0..8 the unfused 4-kernel form with that contraction tile variant. Returns IKF_ERR_BAD_ARGUMENT if unknown. */
 ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 
 #ifdef __cplusplus

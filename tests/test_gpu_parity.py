@@ -132,7 +132,7 @@ def test_full_batch_properties_4096():
     assert torch.equal(full, again)  # deterministic
     # any sub-batch reproduces its rows bit-for-bit (rows are independent; the k-order of the contraction is fixed)
     for lo, hi in [(0, 1), (5, 133), (4000, 4096), (1024, 1536)]:
-        part = s.generate_ik_solutions(P[lo:hi].contiguous(), latent=L[lo:hi].contiguous())
+        part = s.generate_ik_solutions(P[lo:hi].contiguous(), n=(1 if hi - lo == 1 else None), latent=L[lo:hi].contiguous())
         assert torch.equal(part, full[lo:hi])
     # oracle on a slice
     ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:256], lat[:256])
@@ -241,12 +241,12 @@ def _exact_inputs(robot, lay, n, repeat_counts, seed):
 @pytest.mark.parametrize("n", [7, 200])
 def test_exact_ik_matches_oracle_control_flow(n):
     """Whole retry schedule against the oracle's restatement of ikflow_solver.py:119-247,345-411, with injected latents.
-    Random weights make the flow seeds poor, so loose thresholds are used to get a mix of solved/unsolved poses and
+    Random weights make the flow seeds poor, so loose thresholds (0.2 m / 1 rad) are used to get a mix of solved/unsolved poses and
     all three retry rounds; rows whose error sits within 1e-4 relative of a threshold may flip and are excluded."""
     robot, hp, lay, sd = tiny_model(seed=2)
     s = _solver(robot, hp, sd)
     rc = (1, 3, 10)
-    pos_thr, rot_thr = 0.05, 0.3
+    pos_thr, rot_thr = 0.2, 1.0
     poses, lats = _exact_inputs(robot, lay, n, rc, 21)
 
     def flow_fn(latent, poses_tiled):

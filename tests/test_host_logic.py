@@ -1,0 +1,192 @@
+"""CPU tests of the host side: API mirror (assert behaviour of ikflow_solver.py), weight-table validation, chain
+folding, C-ABI library export table.  No compute call reaches the GPU here."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import panda_model, tiny_model
+from ikflow_amd import _lib, config
+from ikflow_amd.engine import fold_chain
+from ikflow_amd.ikflow_solver import IKFlowSolver, draw_latent
+from ikflow_amd.model import (MODEL_DESCRIPTIONS, TINY_MODEL_PARAMS, IkflowModelParameters, hparams_for, key_linear,
+                              layout_from, random_state_dict, validate_state_dict)
+from ikflow_amd.model_loading import get_all_model_names, get_ik_solver, model_filename
+from ikflow_amd.robots import Fetch, FetchArm, Panda, get_robot
+from oracle import kinematics_oracle as ko
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "ikflow_amd.h")).read()
+    declared = set(re.findall(r"\b(ikf_[a-z_0-9]+)\s*\(", header)) - {"ikf_latent_fn"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/ikflow_amd.h but not exported"
+    assert lib.ikf_abi_version() == _lib.IKF_ABI_VERSION
+    assert lib.ikf_dominant_kernel_name().decode() == "k_flow_gemm"
+    assert ctypes.sizeof(_lib.ikf_joint) == 4 + 12 + 48 and ctypes.sizeof(_lib.ikf_model_desc) == 9 * 4 + 2 * 32 + 8 * 64 + 48
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    from ikflow_amd.engine import EngineError
+
+    robot, hp, lay, sd = tiny_model()
+    s = IKFlowSolver(hp, robot)
+    s.load_state_dict_tensors(sd)
+    with pytest.raises(EngineError, match="no CPU path"):
+        s.generate_ik_solutions(torch.zeros(7), n=4)
+    with pytest.raises(EngineError):
+        robot.forward_kinematics(torch.zeros(1, 7))
+    desc = _lib.ikf_model_desc()
+    desc.abi_version = _lib.IKF_ABI_VERSION
+    h = ctypes.c_void_p()
+    assert _lib.load().ikf_create(ctypes.byref(desc), 0, ctypes.byref(h)) == _lib.IKF_ERR_NO_DEVICE
+    assert "no HIP device" in _lib.last_error()
+
+
+def test_solver_argument_asserts_mirror_reference():
+    """ikflow_solver.py:309-326 - every assert fires before any device work."""
+    robot, hp, lay, sd = tiny_model()
+    s = IKFlowSolver(hp, robot)
+    y = torch.zeros(7)
+    with pytest.raises(AssertionError, match="Model weights have not been loaded"):
+        s.generate_ik_solutions(y, n=3)
+    s.load_state_dict_tensors(sd)
+    with pytest.raises(AssertionError):
+        s.generate_ik_solutions([0.0] * 7, n=3)  # y must be a tensor
+    with pytest.raises(AssertionError):
+        s.generate_ik_solutions(y)  # single pose needs n
+    with pytest.raises(AssertionError):
+        s.generate_ik_solutions(torch.zeros(1, 7))  # quirk Q2: [1 x 7] is the single-pose form
+    with pytest.raises(AssertionError):
+        s.generate_ik_solutions(y, n=0)
+    with pytest.raises(AssertionError, match="y must be of shape"):
+        s.generate_ik_solutions(torch.zeros(4, 6))
+    with pytest.raises(AssertionError):
+        s.generate_ik_solutions(y, n=3, latent_scale=1)  # quirk Q1: must be a float
+    with pytest.raises(AssertionError, match="latent must either be"):
+        s.generate_ik_solutions(y, n=3, latent=np.zeros((3, 9)))
+    with pytest.raises(AssertionError, match="refine_solutions is deprecated"):
+        s.generate_ik_solutions(y, n=3, refine_solutions=True)
+    with pytest.raises(AssertionError, match="must be of shape"):
+        s.generate_exact_ik_solutions(torch.zeros(4, 6))
+    with pytest.raises(AssertionError, match="must be a tuple"):
+        s.generate_exact_ik_solutions(torch.zeros(4, 7), repeat_counts=[1, 3])
+    with pytest.raises(AssertionError, match="return_detailed is not currently supported"):
+        s.generate_exact_ik_solutions(torch.zeros(4, 7), return_detailed=True)
+    assert (s.robot.name, s.network_width, s.conditional_size, s.ndof) == ("panda", 9, 8, 7)
+
+
+def test_constructor_asserts():
+    with pytest.raises(AssertionError, match="IkflowModelParameters"):
+        IKFlowSolver({"nb_nodes": 3}, Panda())
+    with pytest.raises(AssertionError, match="Robot type"):
+        IKFlowSolver(TINY_MODEL_PARAMS, "panda")
+    hp = IkflowModelParameters()
+    hp.sigmoid_on_output = True
+    with pytest.raises(AssertionError, match="incompatible"):
+        IKFlowSolver(hp, Panda())
+    hp = IkflowModelParameters()
+    del hp.sigmoid_on_output  # old checkpoints lack it (ikflow_solver.py:43-44)
+    IKFlowSolver(hp, Panda())
+    assert hp.sigmoid_on_output is False
+
+
+def test_draw_latent():
+    torch.manual_seed(0)
+    a = draw_latent("gaussian", 0.75, (5, 7), "cpu")
+    torch.manual_seed(0)
+    assert torch.equal(a, 0.75 * torch.randn((5, 7)))
+    u = draw_latent("uniform", 2.0, (1000, 3), "cpu")
+    assert u.min() >= -2.0 and u.max() <= 2.0
+    with pytest.raises(AssertionError):
+        draw_latent("laplace", 1.0, (2, 2), "cpu")
+    with pytest.raises(AssertionError):
+        draw_latent("gaussian", 0.0, (2, 2), "cpu")
+
+
+def test_state_dict_validation_and_pickle_roundtrip(tmp_path):
+    robot, hp, lay, sd = tiny_model()
+    validate_state_dict(lay, sd)
+    assert len([k for k in sd if k.endswith("weight")]) == lay.nb_nodes * 2 * (lay.n_hidden + 1)
+    assert sd[key_linear(0, 1, 0, "weight")].shape == (256, 4 + 8) and sd[key_linear(0, 2, 2, "weight")].shape == (8, 256)
+    bad = dict(sd)
+    del bad[key_linear(1, 2, 1, "bias")]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        validate_state_dict(lay, bad)
+    bad = dict(sd)
+    bad[key_linear(0, 1, 0, "weight")] = np.zeros((256, 11), np.float32)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        validate_state_dict(lay, bad)
+    # the reference's file format: pickle of {name: torch.Tensor} (ikflow_solver.py:416-418), optionally "nn_model."-prefixed
+    path = tmp_path / "w.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"nn_model." + k: torch.from_numpy(v) for k, v in sd.items()}, f)
+    s = IKFlowSolver(hp, robot)
+    s.load_state_dict(str(path))
+    assert s._model_weights_loaded
+    for k, v in sd.items():
+        assert np.array_equal(s._state_dict_np[k], v)
+    np.savez(tmp_path / "w.npz", **sd)
+    s2 = IKFlowSolver(hp, robot)
+    s2.load_state_dict(str(tmp_path / "w.npz"))
+    assert s2._model_weights_loaded
+    with open(tmp_path / "junk.pkl", "wb") as f:
+        f.write(b"not a pickle")
+    with pytest.raises(pickle.UnpicklingError):
+        IKFlowSolver(hp, robot).load_state_dict(str(tmp_path / "junk.pkl"))
+
+
+def test_model_registry():
+    assert set(get_all_model_names()) == set(MODEL_DESCRIPTIONS)
+    assert model_filename("https://storage.googleapis.com/ikflow_models/atlas_desert-sweep-6.pkl") == "atlas_desert-sweep-6.pkl"
+    hp = hparams_for("fetch_arm__large__mh186_9.25m")
+    assert (hp.nb_nodes, hp.dim_latent_space, hp.coeff_fn_internal_size, hp.softflow_enabled) == (16, 10, 1024, True)
+    with pytest.raises(AssertionError, match="not found in model descriptions"):
+        get_ik_solver("panda_tpm")
+    with pytest.raises(FileNotFoundError):
+        get_ik_solver("panda_lite_tpm")
+    s, hp = get_ik_solver("panda_lite_tpm", synthetic_weights_seed=1)
+    assert s._model_weights_loaded and hp.nb_nodes == 6 and s.robot.name == "panda"
+    with pytest.raises(ValueError):
+        get_robot("atlas")
+
+
+def test_fold_chain_matches_joint_by_joint_fk():
+    """The engine walks actuated joints with the fixed URDF transforms pre-multiplied; same FK as the oracle's walk."""
+    for robot in (Panda(), FetchArm(), Fetch()):
+        joints, tool = fold_chain(robot)
+        assert len(joints) == robot.ndof
+        q = robot.sample_joint_angles(16, 0.0, np.random.default_rng(3)).astype(np.float64)
+        ref = ko.forward_kinematics(robot, torch.from_numpy(q)).numpy()
+        for r in range(q.shape[0]):
+            T = np.eye(4)
+            for (kind, ax, pre), qi in zip(joints, q[r]):
+                F = np.eye(4)
+                F[:3, :4] = pre
+                T = T @ F
+                Mo = np.eye(4)
+                if kind == 1:
+                    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+                    Mo[:3, :3] = np.eye(3) + np.sin(qi) * K + (1 - np.cos(qi)) * (K @ K)
+                else:
+                    Mo[:3, 3] = ax * qi
+                T = T @ Mo
+            F = np.eye(4)
+            F[:3, :4] = tool
+            T = T @ F
+            np.testing.assert_allclose(T[:3, 3], ref[r, :3], atol=1e-12)
+
+
+def test_config_and_device_rule():
+    assert config.DEFAULT_TORCH_DTYPE == torch.float32
+    assert config.DEVICE == ("cuda:0" if torch.cuda.is_available() else "cpu") or config.DEVICE.startswith("cuda:")

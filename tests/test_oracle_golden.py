@@ -1,0 +1,198 @@
+"""CPU tests: pin the oracle against every vector the reference's own tests hold for this path, and against the committed
+fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import torch
+
+from helpers import latents, panda_model, reachable_poses, tiny_model
+from ikflow_amd.model import fixed_linear_transform, freia_permutation, hparams_for, layout_from
+from ikflow_amd.robots import FetchArm, Panda
+from oracle import flow_oracle as fo
+from oracle import kinematics_oracle as ko
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- reference tests/evaluation_utils_test.py:14-32 -----------------------------------------------------------------
+def test_panda_fk_zero_known_answer():
+    robot = Panda()
+    pose = ko.forward_kinematics(robot, torch.zeros((1, 7), dtype=torch.float32))[0]
+    gt = torch.tensor([0.088, 0.0, 0.926, 0.0, 0.92387953, 0.38268343, 0.0], dtype=torch.float32)
+    np.testing.assert_allclose(pose.numpy(), gt.numpy(), atol=1e-5)
+
+
+def test_pose_error_known_answers():
+    robot = Panda()
+    target = torch.tensor([[1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0]])
+    l2, ang = ko.calculate_pose_error(robot, torch.zeros((1, 7)), target)
+    assert abs(l2[0].item() - 1.355440887681938) < 1e-6  # sqrt((1-.088)^2 + 1 + (1-.926)^2)
+    assert abs(ang[0].item() - 3.1415927) < 5e-4
+
+
+# ---- reference tests/evaluation_utils_test.py:34-55 -----------------------------------------------------------------
+def test_calculate_joint_limits_exceeded():
+    configs = torch.tensor([[0, 0, 0], [0, 0, 0], [-2, 0, 0], [0, -1.999, 0], [0, 2.0001, 0]])
+    joint_limits = [(-1, 1), (-2, 2), (-3, 3)]
+    expected = torch.tensor([False, False, True, False, True], dtype=torch.bool)
+    returned = ko.calculate_joint_limits_exceeded(configs, joint_limits)
+    assert returned.dtype == torch.bool and returned.shape == (5,)
+    torch.testing.assert_close(returned, expected)
+
+
+# ---- reference tests/model_test.py:27-44 ----------------------------------------------------------------------------
+def test_panda_joint_limits():
+    upper = [2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973]
+    lower = [-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973]
+    robot = Panda()
+    assert robot.ndof == 7 and robot.name == "panda"
+    for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+        assert abs(lo - lower[i]) < 1e-5 and abs(hi - upper[i]) < 1e-5
+
+
+def test_fixed_linear_transform_scale_is_max_abs_limit():
+    """ikflow/model.py:310-316: M = diag(1/max|lim|) -> rev multiplies column i by max(|lo_i|,|hi_i|)."""
+    robot = Panda()
+    lay = layout_from(hparams_for("panda__full__lp191_5.25m"), robot)
+    M, M_inv, b = fixed_linear_transform(lay, robot)
+    want = [2.8973, 1.7628, 2.8973, 3.0718, 2.8973, 3.7525, 2.8973]
+    np.testing.assert_allclose(np.diag(M_inv), want, rtol=1e-6)
+    assert np.count_nonzero(M_inv - np.diag(np.diag(M_inv))) == 0 and not b.any()
+
+
+# ---- numpy legacy MT19937 permutation tables (FrEIA PermuteRandom(seed=i), ikflow/model.py:339) --------
+PERM_D7 = [[6, 2, 1, 3, 0, 5, 4], [6, 2, 1, 0, 4, 3, 5], [4, 1, 3, 2, 6, 5, 0], [4, 6, 5, 3, 1, 0, 2], [4, 6, 3, 0, 1, 5, 2],
+           [6, 2, 4, 1, 0, 5, 3], [4, 5, 6, 0, 3, 1, 2], [2, 5, 0, 6, 3, 1, 4], [2, 0, 6, 5, 1, 4, 3], [5, 1, 2, 3, 0, 4, 6],
+           [2, 6, 0, 3, 4, 5, 1], [2, 5, 4, 6, 3, 0, 1]]
+PERM_D10 = [[2, 8, 4, 9, 1, 6, 7, 3, 0, 5], [2, 9, 6, 4, 0, 3, 1, 7, 8, 5], [4, 1, 5, 0, 7, 2, 3, 6, 9, 8],
+            [5, 4, 1, 2, 9, 6, 7, 0, 3, 8], [3, 8, 4, 9, 2, 6, 0, 1, 5, 7], [9, 5, 2, 4, 7, 1, 0, 8, 6, 3],
+            [8, 1, 7, 0, 6, 5, 2, 4, 3, 9], [8, 5, 0, 2, 1, 9, 7, 3, 6, 4], [8, 6, 9, 0, 2, 5, 7, 1, 4, 3],
+            [8, 4, 7, 2, 1, 9, 3, 0, 6, 5], [8, 2, 5, 6, 3, 1, 0, 7, 4, 9], [7, 8, 2, 6, 4, 5, 1, 3, 0, 9],
+            [5, 8, 7, 0, 4, 9, 3, 2, 1, 6], [3, 5, 6, 1, 4, 7, 8, 9, 0, 2], [3, 9, 0, 5, 4, 2, 1, 7, 6, 8],
+            [2, 6, 1, 3, 7, 0, 9, 4, 5, 8]]
+
+
+def test_permutation_tables():
+    for i, p in enumerate(PERM_D7):
+        assert freia_permutation(7, i).tolist() == p
+    for i, p in enumerate(PERM_D10):
+        assert freia_permutation(10, i).tolist() == p
+    state = np.random.get_state()[1][:4].copy()
+    freia_permutation(7, 3)
+    assert (np.random.get_state()[1][:4] == state).all()  # numpy's global RNG is left alone
+
+
+# ---- work figures of SURVEY 8(d) / BASELINE.md section 3 --------------------------------------------------------------
+def test_algorithmic_work_figures():
+    lay = layout_from(hparams_for("panda__full__lp191_5.25m"), Panda())
+    assert (lay.n_weights(), lay.flops_per_solution(), lay.weight_bytes(), lay.row_io_bytes()) == (50786304, 101572608, 203440800, 84)
+    lay = layout_from(hparams_for("fetch_arm__large__mh186_9.25m"), FetchArm())
+    assert (lay.n_weights(), lay.flops_per_solution(), lay.weight_bytes(), lay.row_io_bytes()) == (67862528, 135725056, 271844608, 96)
+    from ikflow_amd.model import TINY_MODEL_PARAMS
+
+    lay = layout_from(TINY_MODEL_PARAMS, Panda())
+    assert (lay.n_weights(), lay.flops_per_solution(), lay.weight_bytes()) == (426240, 852480, 1717464)
+    assert (lay.split1, lay.split2, lay.dim_cond) == (4, 5, 8)
+
+
+# ---- committed fixtures -----------------------------------------------------------------------------------------------
+def test_flow_oracle_reproduces_fixtures():
+    for name, model in (("tiny_flow.npz", tiny_model), ("panda_flow.npz", panda_model)):
+        z = np.load(os.path.join(GOLD, name))
+        robot, hp, lay, sd = model(seed=int(z["weights_seed"]))
+        poses, lat = torch.from_numpy(z["poses"]), torch.from_numpy(z["latent"])
+        out = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
+        np.testing.assert_allclose(out.numpy(), z["q_clamped"], atol=2e-6)
+        out_nc = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+        np.testing.assert_allclose(out_nc.numpy(), z["q_unclamped"], atol=1e-5, rtol=1e-5)
+        cond = torch.cat([poses, torch.zeros(poses.shape[0], 1)], 1).numpy()
+        o64 = fo.run_inference_f64(sd, lay, robot.actuated_joints_limits, z["latent"], cond, True)
+        assert np.abs(o64 - z["q_clamped"]).max() < 1e-5  # fp32 path vs fp64 twin
+
+
+def test_kinematics_oracle_reproduces_fixtures():
+    z = np.load(os.path.join(GOLD, "panda_kinematics.npz"))
+    robot = Panda()
+    q = torch.from_numpy(z["q"])
+    np.testing.assert_allclose(ko.forward_kinematics(robot, q).numpy(), z["fk"], atol=2e-6)
+    pe, re = ko.calculate_pose_error(robot, torch.from_numpy(z["q0"]), torch.from_numpy(z["target"]))
+    np.testing.assert_allclose(pe.numpy(), z["pos_err"], atol=1e-6)
+    np.testing.assert_allclose(re.numpy(), z["rot_err"], atol=2e-5)
+    lm = ko.lm_step(robot, torch.from_numpy(z["target"]).double(), torch.from_numpy(z["q0"]).double())
+    np.testing.assert_allclose(lm.numpy(), z["lm_step_f64"], atol=1e-9)
+    np.testing.assert_allclose(ko.jacobian(robot, q.double()).numpy(), z["jac_f64"], atol=1e-12)
+
+
+# ---- oracle self-consistency --------------------------------------------------------------------------------------------
+def test_flow_oracle_fp32_vs_fp64_and_properties():
+    robot, hp, lay, sd = tiny_model(seed=1)
+    n = 64
+    _, poses = reachable_poses(robot, n, 3)
+    lat = latents(n, lay.dim, 4)
+    cond = torch.cat([poses, torch.zeros(n, 1)], 1)
+    o32 = fo.flow_inverse_torch(sd, lay, lat, cond).numpy()
+    o64 = fo.flow_inverse_f64(sd, lay, lat.numpy(), cond.numpy())
+    assert np.abs(o32 - o64).max() < 2e-5
+    # reference tests/ikflow_solver_test.py:89-117 as properties of the restatement
+    ys = torch.zeros(2, 7)
+    z = torch.zeros(2, lay.dim)
+    a = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, ys, z, clamp=False)
+    torch.testing.assert_close(a[0], a[1])
+    ys2 = torch.tensor([[0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0]], dtype=torch.float32)
+    b = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, ys2, z, clamp=False)
+    for j in range(7):
+        assert ((b[1] - b[0, j]).abs() < 1e-8).sum().item() == 0
+
+
+def test_jacobian_is_derivative_of_fk():
+    for robot in (Panda(), FetchArm()):
+        q = torch.tensor(robot.sample_joint_angles(8, 0.01, np.random.default_rng(2))).double()
+        J = ko.jacobian(robot, q)
+        eps = 1e-6
+        for i in range(robot.ndof):
+            dq = torch.zeros_like(q)
+            dq[:, i] = eps
+            p1, p0 = ko.forward_kinematics(robot, q + dq), ko.forward_kinematics(robot, q - dq)
+            assert ((p1[:, :3] - p0[:, :3]) / (2 * eps) - J[:, 3:6, i]).abs().max() < 1e-6
+
+
+def test_lm_step_converges_and_respects_limits():
+    robot = Panda()
+    qt = torch.tensor(robot.sample_joint_angles(200, 0.05, np.random.default_rng(7)))
+    poses = ko.forward_kinematics(robot, qt)
+    q = ko.clamp_to_joint_limits(robot, qt + 0.05 * torch.randn(200, 7, generator=torch.Generator().manual_seed(8)))
+    for _ in range(3):
+        q = ko.lm_step(robot, poses, q)
+    pe, re = ko.calculate_pose_error(robot, q, poses)
+    assert ((pe < 1e-3) & (re < 0.01)).float().mean().item() > 0.95
+    assert torch.equal(q, ko.clamp_to_joint_limits(robot, q))
+
+
+def test_geodesic_floor_and_wrap():
+    q = torch.tensor([[1.0, 0, 0, 0]])
+    d_same = ko.geodesic_distance_between_quaternions(q, q)
+    assert 9e-4 < d_same.item() < 1.1e-3  # acos clamp at 1-1e-7 -> ~9.8e-4 rad floor in fp32
+    d_neg = ko.geodesic_distance_between_quaternions(q, -q)  # same rotation, opposite sign: wraps back to ~0
+    assert d_neg.item() < 2e-3
+    d_pi = ko.geodesic_distance_between_quaternions(q, torch.tensor([[0.0, 1.0, 0, 0]]))
+    assert abs(d_pi.item() - math.pi) < 1e-5
+
+
+def test_exact_ik_oracle_control_flow_invariants():
+    """ikflow_solver.py:197,217-225: unsolved rows stay 0, solved rows meet thresholds, later rounds only touch invalid rows."""
+    robot, hp, lay, sd = tiny_model(seed=2)
+    n, rc = 40, (1, 3, 10)
+    _, poses = reachable_poses(robot, n, 21)
+    lats = [latents(n * r, lay.dim, 100 + i) for i, r in enumerate(rc)]
+
+    def flow_fn(latent, pt):
+        return fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, pt, latent[: pt.shape[0]], clamp=True)
+
+    sol, valid = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, 0.2, 1.0)
+    assert 0 < int(valid.sum()) < n
+    assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
+    pe, re = ko.calculate_pose_error(robot, sol[valid], poses[valid])
+    assert (pe < 0.2).all() and (re < 1.0).all()
+    sol1, valid1 = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats[:1], (1,), 0.2, 1.0)
+    assert torch.equal(sol[valid1], sol1[valid1]) and bool((valid | ~valid1).all())
