@@ -220,8 +220,9 @@ def calculate_joint_limits_exceeded(configs: torch.Tensor, joint_limits) -> torc
 # exact-IK control loop (ikflow_solver.py:119-247, 345-411), flow seeds supplied by a callback so the same
 # loop can be driven by the torch oracle flow (CPU parity) or by recorded seeds.
 # ---------------------------------------------------------------------------------------------------
-def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_opt_steps_max=3):
-    """One call of _generate_exact_ik_solutions given the clamped flow seeds q [n*R x ndof] (tile-major)."""
+def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_opt_steps_max=3, lm_dtype=torch.float32):
+    """One call of _generate_exact_ik_solutions given the clamped flow seeds q [n*R x ndof] (tile-major).
+    lm_dtype=float64 evaluates each LM step in double and rounds q back to float32 (what the HIP kernel does)."""
     n = target_poses.shape[0]
     q = seeds_q.clone()
     poses_tiled = target_poses.repeat((repeat_count, 1))
@@ -230,7 +231,8 @@ def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_
     n_invalid = n
     for _ in range(n_opt_steps_max):
         assert len(q) == n_invalid * repeat_count
-        q = lm_step(robot, poses_tiled, q)
+        q = lm_step(robot, poses_tiled.to(lm_dtype), q.to(lm_dtype)).to(torch.float32)
+        q = clamp_to_joint_limits(robot, q)
         pos_err, rot_err = calculate_pose_error(robot, q, poses_tiled)
         valids_tiled = torch.logical_and(pos_err < pos_thr, rot_err < rot_thr)
         valids_i = torch.zeros(n_invalid, dtype=torch.bool)
@@ -250,13 +252,14 @@ def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_
     return final_solutions, final_valids
 
 
-def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torch.Tensor], repeat_counts=(1, 3, 10), pos_thr=1e-3, rot_thr=0.1):
+def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torch.Tensor], repeat_counts=(1, 3, 10), pos_thr=1e-3, rot_thr=0.1,
+                                lm_dtype=torch.float32):
     """Retry schedule of ikflow_solver.py:345-411.  ``flow_fn(latent, poses_tiled) -> clamped q`` ;
     ``latents[r]`` is the [n_r*R_r x D] latent the reference would have drawn in round r."""
     n = target_poses.shape[0]
     R0 = repeat_counts[0]
     seeds = flow_fn(latents[0], target_poses.repeat((R0, 1)))
-    solutions, valids = exact_round(robot, seeds, target_poses, R0, pos_thr, rot_thr)
+    solutions, valids = exact_round(robot, seeds, target_poses, R0, pos_thr, rot_thr, lm_dtype=lm_dtype)
     if valids.all():
         return solutions, valids
     for r in range(1, len(repeat_counts)):
@@ -265,7 +268,7 @@ def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torc
         if missing.shape[0] == 0:
             break
         seeds = flow_fn(latents[r][: missing.shape[0] * R], missing.repeat((R, 1)))
-        new_sol, new_valid = exact_round(robot, seeds, missing, R, pos_thr, rot_thr)
+        new_sol, new_valid = exact_round(robot, seeds, missing, R, pos_thr, rot_thr, lm_dtype=lm_dtype)
         not_valid = torch.logical_not(valids)
         solutions[not_valid, :] = new_sol
         valids[not_valid] = new_valid

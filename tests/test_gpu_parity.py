@@ -253,20 +253,24 @@ def test_exact_ik_matches_oracle_control_flow(n):
         return fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses_tiled, latent[: poses_tiled.shape[0]], clamp=True)
 
     ref_sol, ref_valid = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, pos_thr, rot_thr)
+    # same schedule with each LM step evaluated in fp64 (what the kernel does): the comparator for solution VALUES
+    ref_sol64, ref_valid64 = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, pos_thr, rot_thr, lm_dtype=torch.float64)
     sol, valid = s.generate_exact_ik_solutions(
         poses.to(DEV), repeat_counts=rc, pos_error_threshold=pos_thr, rot_error_threshold=rot_thr,
         latents=[l.to(DEV) for l in lats],
     )
     sol, valid = sol.cpu(), valid.cpu()
     assert sol.shape == (n, 7) and valid.dtype == torch.bool and valid.shape == (n,)
-    agree = valid == ref_valid
-    frac = agree.float().mean().item()
-    print(f"exact n={n}: valid {int(valid.sum())}/{n} (oracle {int(ref_valid.sum())}), agreement {frac:.4f}")
-    assert 0 < int(ref_valid.sum()) and frac >= 0.97
-    both = agree & valid
-    # solutions of poses solved by both at the same point of the schedule agree to LM-step accuracy
-    d = (sol[both] - ref_sol[both]).abs().max(1).values
-    assert (d <= 1e-3).float().mean().item() >= 0.97
+    frac32 = (valid == ref_valid).float().mean().item()
+    frac64 = (valid == ref_valid64).float().mean().item()
+    print(f"exact n={n}: valid {int(valid.sum())}/{n} (oracle fp32-LM {int(ref_valid.sum())}, fp64-LM {int(ref_valid64.sum())}), "
+          f"agreement {frac32:.4f} / {frac64:.4f}")
+    assert 0 < int(ref_valid.sum()) < n
+    assert frac32 >= 0.95 and frac64 >= 0.97
+    both = (valid == ref_valid64) & valid
+    d = (sol[both] - ref_sol64[both]).abs().max(1).values
+    print(f"   solution |hip - oracle(fp64 LM)|: max {d.max().item():.2e}, frac <= 1e-4: {(d <= 1e-4).float().mean().item():.3f}")
+    assert (d <= 1e-4).float().mean().item() >= 0.95  # a row can differ when a near-threshold repeat flips which one "wins"
     assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))  # unsolved rows stay 0 (ikflow_solver.py:197)
     # every reported-valid solution really meets the thresholds and the joint limits
     pe, re = ko.calculate_pose_error(robot, sol[valid], poses[valid])
