@@ -83,6 +83,22 @@ def cpu_baseline(sd, layout, limits, poses_cpu, latent_cpu, budget_s):
     }
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per dominant-kernel launch from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json:
+    separate FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 x2 read correction applied). PMC counters
+    cannot be collected from inside the process, so this is the recorded figure, or None if no summary is present."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f).get("dominant_kernel_traffic_bytes_per_launch"), os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,6 +176,7 @@ def main():
     value = world * B * args.steps / elapsed
     flow_tflops = value / world * layout.flops_per_solution() / 1e12
 
+    traffic, traffic_src = pmc_traffic_per_launch() if args.batch == 4096 else (None, None)
     extra = {"flow_tflops_per_gpu": round(flow_tflops, 2), "gemm_ms": round(gemm_ms, 5),
              "gemm_launches_per_step": 2 * layout.nb_nodes * (layout.n_hidden - 1)}
     if args.extras and rank == 0:
@@ -181,7 +198,8 @@ def main():
         "config": {"workload": f"{args.model} generate_ik_solutions, B={B} poses per GPU per step, clamp_to_joint_limits",
                    "global_batch": world * B, "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": eng.dominant_kernel_name(),
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
+                     "traffic_source": traffic_src, "kernel": eng.dominant_kernel_name(),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms},
         "extra": extra,
     }
