@@ -11,7 +11,7 @@
 //   k_flow_finalize       after the last subnet: "finish the previous subnet" + FixedLinearTransform^-1, [:, :ndof],
 //                         clamp_to_joint_limits (ikflow_solver.py:99-102)
 //
-// The K loop is the 3-stage / one-barrier-per-tile pipeline of k_gemm_lrelu_p3 (flow_kernels.hip), 8 waves of 64x32.
+// The K loop is the 3-stage / one-barrier-per-tile pipeline of k_gemm_lrelu_p3 (flow_kernels.hip).
 // (Generating the A operand of the first hidden contraction on the fly was measured and rejected: its ~110 VALU
 // instructions per wave per K tile did not stay in the MFMA shadow - 98 us against 65 us + a 5 us entry kernel.)
 #include <type_traits>
@@ -23,10 +23,23 @@ namespace ikf {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int FBM = 128, FBN = 128, FBK = 32, FWAVES_M = 2, FWAVES_N = 4;  // 8 waves of 64x32
-constexpr int FNT = FWAVES_M * FWAVES_N * 64;
-constexpr int FKH = (FNT / 64) / (FBM / 32);  // column splits of the partial-sum epilogue (= slots per tile)
-constexpr int ROWBUF = 16;                    // floats per row in the small per-row LDS arrays (>= D, >= n_out)
+constexpr int FBK = 32;
+constexpr int ROWBUF = 16;  // floats per row in the small per-row LDS arrays (>= D, >= n_out)
+
+// Tile configurations of the hidden contraction, chosen by the row count so that the launch has >= 256 workgroups
+// whenever the batch allows it (one wave of tiles over the 256 CUs):
+//   0: 128x128, 8 waves of 64x32   (rows >= 4096)
+//   1:  64x128, 8 waves of 32x32   (rows >= 2048)
+//   2:  64x64,  4 waves of 32x32   (rows >= 1024)
+//   3:  32x64,  2 waves of 32x32   (smaller batches)
+template <int CFG> struct TileCfg;
+template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 4; };
+template <> struct TileCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M = 2, WAVES_N = 4; };
+template <> struct TileCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2; };
+template <> struct TileCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2; };
+constexpr int kNumTileCfg = 4;
+static const int kCfgBM[kNumTileCfg] = {128, 64, 64, 32};
+static const int kCfgBN[kNumTileCfg] = {128, 128, 64, 64};
 
 // ---------------------------------------------------------------------------------------------------------------
 // Finish a pending coupling for R rows starting at m0 and leave the new state rows in LDS sn[R][ROWBUF].
@@ -161,9 +174,15 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
 // ---------------------------------------------------------------------------------------------------------------
 // hidden contraction; EPI_RED: reduce the last Linear in the epilogue instead of storing the activation
 // ---------------------------------------------------------------------------------------------------------------
-template <bool EPI_RED>
-__global__ __launch_bounds__(FNT) void k_flow_gemm(FusedGemmArgs g) {
-  constexpr int BM = FBM, BN = FBN, BK = FBK, NT = FNT;
+template <bool EPI_RED, int CFG>
+__global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) void k_flow_gemm(FusedGemmArgs g) {
+  using TC = TileCfg<CFG>;
+  constexpr int BM = TC::BM, BN = TC::BN, BK = FBK, FWAVES_M = TC::WAVES_M, FWAVES_N = TC::WAVES_N;
+  constexpr int NT = FWAVES_M * FWAVES_N * 64;
+  // partial-sum epilogue: one slot = 64 columns for EVERY tile configuration, so the last Linear is summed in the same
+  // order whatever the batch size (results are bit-identical across batch sizes)
+  constexpr int FKH = BN / 64;
+  static_assert(BN % 64 == 0 && (BM / 32) * FKH <= NT / 64, "not enough waves for the partial-sum epilogue");
   constexpr int WM = BM / FWAVES_M, WN = BN / FWAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int LDK = BK + 4;
@@ -315,9 +334,20 @@ __global__ __launch_bounds__(FNT) void k_flow_gemm(FusedGemmArgs g) {
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
 
-  IKF_GLOAD(0)
-  IKF_LSTORE(0)
-  if (KT > 1) IKF_GLOAD(BK)
+  // prologue: the (cold) loads of tile 0 and tile 1 are issued back to back so their miss latencies overlap
+  {
+    floatx4 ra0[A_F4], rb0[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) ra0[i] = *reinterpret_cast<const floatx4*>(a_src[i]);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) rb0[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K);
+    if (KT > 1) IKF_GLOAD(BK)
+    float* sp0 = smem + lds_t;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + i * RS * LDK) = ra0[i];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + BM * LDK + i * RS * LDK) = rb0[i];
+  }
   __syncthreads();
   IKF_FRAG(fa0, fb0, 0, 0)
 
@@ -388,28 +418,30 @@ __global__ __launch_bounds__(FNT) void k_flow_gemm(FusedGemmArgs g) {
     }
     __syncthreads();
     constexpr int RB = BM / 32;
-    constexpr int CW = BN / FKH;  // columns per split
-    const int rb = wave % RB, kh = wave / RB;
-    floatx16 pacc;
+    constexpr int CW = 64;  // columns per slot
+    if (wave < RB * FKH) {  // wave-uniform: the remaining waves have no slot
+      const int rb = wave % RB, kh = wave / RB;
+      floatx16 pacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-    const float* pa = Wl + (lane & 31) * LDT + kh * CW + (lane >> 5) * 4;
-    const float* pb = T + (rb * 32 + (lane & 31)) * LDT + kh * CW + (lane >> 5) * 4;
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      const float* pa = Wl + (lane & 31) * LDT + kh * CW + (lane >> 5) * 4;
+      const float* pb = T + (rb * 32 + (lane & 31)) * LDT + kh * CW + (lane >> 5) * 4;
 #pragma unroll
-    for (int ks = 0; ks < CW / 8; ++ks) {
-      const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
-      const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
-      pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
-    }
-    // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7
-    float* pout = g.P_out + (size_t)(tn * FKH + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE;
+      for (int ks = 0; ks < CW / 8; ++ks) {
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+      }
+      // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7
+      float* pout = g.P_out + (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const int o = (r & 3) + 8 * (r >> 2) + row_h;
-      pout[o] = pacc[r];
+      for (int r = 0; r < 8; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + row_h;
+        pout[o] = pacc[r];
+      }
     }
   }
 }
@@ -434,14 +466,31 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-int fused_slots_per_tile() { return FKH; }
-int fused_tile_n() { return FBN; }
+int fused_pick_cfg(long long rows, int width) {
+  for (int c = 0; c < kNumTileCfg; ++c) {
+    if (width % kCfgBN[c] != 0) continue;
+    const long long tiles = ((rows + kCfgBM[c] - 1) / kCfgBM[c]) * (width / kCfgBN[c]);
+    if (tiles >= 256) return c;
+  }
+  for (int c = kNumTileCfg - 1; c >= 0; --c)
+    if (width % kCfgBN[c] == 0) return c;
+  return -1;
+}
+int fused_slots(int cfg, int width) { (void)cfg; return width / 64; }
+int fused_max_slots(int width) {
+  int m = 0;
+  for (int c = 0; c < kNumTileCfg; ++c)
+    if (width % kCfgBN[c] == 0 && fused_slots(c, width) > m) m = fused_slots(c, width);
+  return m;
+}
 const char* fused_kernel_name() { return "k_flow_gemm"; }
 
-template <bool EPI_RED>
+template <bool EPI_RED, int CFG>
 static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = (size_t)3 * (FBM + FBN) * (FBK + 4) * sizeof(float);
-  auto kern = k_flow_gemm<EPI_RED>;
+  using TC = TileCfg<CFG>;
+  constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
+  constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (FBK + 4) * sizeof(float);
+  auto kern = k_flow_gemm<EPI_RED, CFG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -449,16 +498,21 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const long long tiles_m = ((long long)a.M + FBM - 1) / FBM;
-  const long long grid = tiles_m * (a.N / FBN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(FNT), smem, s, a);
+  const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
+  const long long grid = tiles_m * (a.N / TC::BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_flow_gemm(bool epi_red, const FusedGemmArgs& a, hipStream_t s) {
+hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.N % FBN != 0 || a.K % FBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
-  return epi_red ? launch_fg<true>(a, s) : launch_fg<false>(a, s);
+  if (cfg < 0 || cfg >= kNumTileCfg || a.N % kCfgBN[cfg] != 0 || a.K % FBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
+  switch (cfg) {
+    case 0: return epi_red ? launch_fg<true, 0>(a, s) : launch_fg<false, 0>(a, s);
+    case 1: return epi_red ? launch_fg<true, 1>(a, s) : launch_fg<false, 1>(a, s);
+    case 2: return epi_red ? launch_fg<true, 2>(a, s) : launch_fg<false, 2>(a, s);
+    default: return epi_red ? launch_fg<true, 3>(a, s) : launch_fg<false, 3>(a, s);
+  }
 }
 
 hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s) {

@@ -32,6 +32,7 @@ struct ikf_model {
   FlowDims dims{};
   bool loaded = false;
   int gemm_variant = -1;  // -1 = choose by batch size
+  int tile_cfg = -1;      // fused pipeline: -1 = choose by batch size, 0..3 forced (variant 100..103)
 
   // packed weights (one arena)
   float* arena = nullptr;
@@ -350,7 +351,7 @@ static ikf_status ensure_scratch(ikf_model* m, long long rows) {
   IKF_HIP(hipMalloc(&m->hA, sizeof(float) * (size_t)want * m->dims.width));
   IKF_HIP(hipMalloc(&m->hB, sizeof(float) * (size_t)want * m->dims.width));
   IKF_HIP(hipMalloc(&m->xbuf2, sizeof(float) * (size_t)want * m->dims.D));
-  const size_t slots = (size_t)(m->dims.width / fused_tile_n()) * fused_slots_per_tile();
+  const size_t slots = (size_t)(fused_max_slots(m->dims.width) > 0 ? fused_max_slots(m->dims.width) : 1);
   IKF_HIP(hipMalloc(&m->pbuf, sizeof(float) * slots * (size_t)want * IKF_PSTRIDE));
   m->chunk_rows = want;
   return IKF_OK;
@@ -380,9 +381,15 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
 
 extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
-  if (variant != 100 && (variant < -1 || variant >= gemm_variant_count()))
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused)");
+  if (variant >= 100 && variant <= 104) {  // fused pipeline; 100 = tile by batch size, 101..104 = tile config 0..3
+    m->gemm_variant = 100;
+    m->tile_cfg = variant - 101;
+    return IKF_OK;
+  }
+  if (variant < -1 || variant >= gemm_variant_count())
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..104 fused)");
   m->gemm_variant = variant;
+  m->tile_cfg = -1;
   return IKF_OK;
 }
 
@@ -410,7 +417,7 @@ static const float* chain_hi(const ikf_model* m) {
 static bool fused_ok(const ikf_model* m) {
   const FlowDims& d = m->dims;
   if (m->gemm_variant >= 0 && m->gemm_variant != 100) return false;
-  return d.n_hidden >= 2 && d.width % fused_tile_n() == 0 && d.D <= 16 && 2 * d.L2 <= 16 &&
+  return d.n_hidden >= 2 && fused_pick_cfg(128, d.width) >= 0 && d.D <= 16 && 2 * d.L2 <= 16 &&
          d.L1 + d.n_pose >= 8 && d.L2 + d.n_pose <= 15;
 }
 
@@ -421,7 +428,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
-  const int slots = (d.width / fused_tile_n()) * fused_slots_per_tile();
+  const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width);
+  const int slots = fused_slots(cfg, d.width);
   PendingCoupling pend{};
   pend.P = nullptr;
   const float* x_src = d_latent + (size_t)r0 * d.D;
@@ -448,7 +456,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
       const bool last = (l == n_mid - 1);
       g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
       IKF_HIP(prof_mark(m, s));
-      IKF_HIP(launch_flow_gemm(last, g, s));
+      IKF_HIP(launch_flow_gemm(last, cfg, g, s));
       IKF_HIP(prof_mark(m, s));
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
@@ -686,7 +694,7 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = m->chunk_rows * IKF_PSTRIDE;
   }
   auto launch = [&]() -> hipError_t {
-    if (fused) return launch_flow_gemm(true, g, s);
+    if (fused) return launch_flow_gemm(true, (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(rows, m->dims.width), g, s);
     return launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width,
                              m->dims.slope, s);
   };

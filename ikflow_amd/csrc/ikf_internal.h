@@ -113,10 +113,11 @@ struct FinalizeArgs {
   int clamp_limits;
   float* q_out;        // [M][ndof]
 };
-int fused_slots_per_tile();  // partial-sum slots one column tile produces
-int fused_tile_n();
+int fused_pick_cfg(long long rows, int width);  // tile configuration for a batch (-1: width not supported)
+int fused_slots(int cfg, int width);            // partial-sum slots that configuration produces per row
+int fused_max_slots(int width);
 hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s);
-hipError_t launch_flow_gemm(bool epi_red, const FusedGemmArgs& a, hipStream_t s);
+hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s);
 hipError_t launch_flow_finalize(const FinalizeArgs& a, hipStream_t s);
 const char* fused_kernel_name();
 

@@ -130,10 +130,17 @@ def test_full_batch_properties_4096():
     full = s.generate_ik_solutions(P, latent=L)
     again = s.generate_ik_solutions(P, latent=L)
     assert torch.equal(full, again)  # deterministic
-    # any sub-batch reproduces its rows bit-for-bit (rows are independent; the k-order of the contraction is fixed)
-    for lo, hi in [(0, 1), (5, 133), (4000, 4096), (1024, 1536)]:
+    # rows are independent: any sub-batch reproduces its rows - bit-for-bit when it runs in the same tile configuration
+    # (the k-order of every contraction and the 64-column slot order of the last Linear are fixed), and in any case
+    # far inside the parity tolerance
+    for lo, hi in [(0, 1), (5, 133), (4000, 4096), (1024, 1536), (0, 2048)]:
+        part = s.generate_ik_solutions(P[lo:hi].contiguous(), n=(1 if hi - lo == 1 else None), latent=L[lo:hi].contiguous())
+        assert (part - full[lo:hi]).abs().max().item() <= 2e-6
+    s.engine(DEV).set_gemm_variant(101)  # pin the 128x128 tile configuration: now bitwise
+    for lo, hi in [(0, 1), (5, 133), (4000, 4096)]:
         part = s.generate_ik_solutions(P[lo:hi].contiguous(), n=(1 if hi - lo == 1 else None), latent=L[lo:hi].contiguous())
         assert torch.equal(part, full[lo:hi])
+    s.engine(DEV).set_gemm_variant(-1)
     # oracle on a slice
     ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:256], lat[:256])
     assert (full[:256].cpu() - ref).abs().max().item() <= FLOW_TOL
