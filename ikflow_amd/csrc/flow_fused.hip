@@ -23,6 +23,15 @@ namespace ikf {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// optional in-kernel timeline (tools/gemm_probe.hip builds with -DIKF_TRACE): thread 0 of every workgroup stores the
+// shader clock at a few points of k_flow_gemm into ikf_trace_buf[block][64]
+#ifdef IKF_TRACE
+__device__ unsigned long long* ikf_trace_buf = nullptr;
+#define IKF_TSTAMP(i) if (threadIdx.x == 0 && ikf_trace_buf) ikf_trace_buf[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+#else
+#define IKF_TSTAMP(i)
+#endif
+
 constexpr int FBK = 32;
 constexpr int ROWBUF = 16;  // floats per row in the small per-row LDS arrays (>= D, >= n_out)
 
@@ -236,28 +245,32 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
   const int fragB = BM * LDK + (wn + (lane & 31)) * LDK + (lane >> 5) * 4;
   const int KT = K / BK;
 
-  floatx4 ra[A_F4], rb[B_F4];
+  floatx4 ra[2][A_F4], rb[2][B_F4];  // two staging sets: global loads run two K tiles ahead of their LDS write
   floatx4 fa0[MI], fb0[NI], fa1[MI], fb1[NI];
 
-#define IKF_GLOAD(koff)                                                                                           \
+#define IKF_GLOAD(S, koff)                                                                                        \
   {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[i] = *reinterpret_cast<const floatx4*>(a_src[i] + (koff)); \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[S][i] = *reinterpret_cast<const floatx4*>(a_src[i] + (koff)); \
     _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
-        rb[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (koff));                        \
+        rb[S][i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (koff));                     \
   }
-#define IKF_LSTORE(stage)                                                                                         \
+#define IKF_LSTORE(S, stage)                                                                                      \
   {                                                                                                               \
     float* sp_ = smem + (stage) * STAGE + lds_t;                                                                  \
-    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp_ + i * RS * LDK) = ra[i];      \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp_ + i * RS * LDK) = ra[S][i];   \
     _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
-        *reinterpret_cast<floatx4*>(sp_ + BM * LDK + i * RS * LDK) = rb[i];                                       \
+        *reinterpret_cast<floatx4*>(sp_ + BM * LDK + i * RS * LDK) = rb[S][i];                                    \
   }
+#if defined(IKF_ABLATE) && IKF_ABLATE == 3
+#define IKF_FRAG(FA, FB, stage, kk) {}
+#else
 #define IKF_FRAG(FA, FB, stage, kk)                                                                               \
   {                                                                                                               \
     const float* sp_ = smem + (stage) * STAGE + (kk) * 8;                                                         \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = *reinterpret_cast<const floatx4*>(sp_ + fragA + i * 32 * LDK); \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = *reinterpret_cast<const floatx4*>(sp_ + fragB + j * 32 * LDK); \
   }
+#endif
 #define IKF_MFMA4(FA, FB)                                                                                         \
   {                                                                                                               \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {                \
@@ -270,15 +283,18 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 
   // One K tile; HAS1/HAS2 (tile kt+1 / kt+2 exist) are compile-time so the steady-state body is branch-free and the
   // sched_group_barrier sequences pin a k-MFMA : 1-memory-op interleave on both sides of the barrier.
-  auto k_tile = [&](auto has1_c, auto has2_c, int kt, int cur, int nxt) {
-    constexpr bool HAS1 = decltype(has1_c)::value, HAS2 = decltype(has2_c)::value;
+  // tile kt+1 sits in register set S (loaded two iterations ago) and is written to LDS stage nxt; the freed set is
+  // refilled with tile kt+3
+  auto k_tile = [&](auto has1_c, auto has3_c, auto set_c, int kt, int cur, int nxt) {
+    constexpr bool HAS1 = decltype(has1_c)::value, HAS2 = decltype(has3_c)::value;
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int kk = 0; kk < NKK / 2; ++kk) {
       if (kk & 1) { IKF_FRAG(fa0, fb0, cur, kk + 1) } else { IKF_FRAG(fa1, fb1, cur, kk + 1) }
       if (kk & 1) { IKF_MFMA4(fa1, fb1) } else { IKF_MFMA4(fa0, fb0) }
       if (kk == 0) {
-        if (HAS1) IKF_LSTORE(nxt)
-        if (HAS2) IKF_GLOAD((kt + 2) * BK)
+        if (HAS1) IKF_LSTORE(S, nxt)
+        if (HAS2) IKF_GLOAD(S, (kt + 3) * BK)
       }
     }
     {
@@ -310,7 +326,9 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
         }
       }
     }
+#if !defined(IKF_ABLATE) || IKF_ABLATE != 1
     __syncthreads();
+#endif
 #pragma unroll
     for (int kk = NKK / 2; kk < NKK; ++kk) {
       if (kk + 1 < NKK) {
@@ -334,14 +352,16 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
   using T_ = std::integral_constant<bool, true>;
   using F_ = std::integral_constant<bool, false>;
 
-  // prologue: the (cold) loads of tile 0 and tile 1 are issued back to back so their miss latencies overlap
+  // prologue: the (cold) loads of tiles 0, 1 and 2 are issued back to back so their miss latencies overlap
+  IKF_TSTAMP(0)
   {
     floatx4 ra0[A_F4], rb0[B_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) ra0[i] = *reinterpret_cast<const floatx4*>(a_src[i]);
 #pragma unroll
     for (int i = 0; i < B_F4; ++i) rb0[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K);
-    if (KT > 1) IKF_GLOAD(BK)
+    if (KT > 1) IKF_GLOAD(1, BK)       // tile 1 -> set 1 (stored by iteration 0)
+    if (KT > 2) IKF_GLOAD(0, 2 * BK)   // tile 2 -> set 0 (stored by iteration 1)
     float* sp0 = smem + lds_t;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + i * RS * LDK) = ra0[i];
@@ -349,21 +369,39 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     for (int i = 0; i < B_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + BM * LDK + i * RS * LDK) = rb0[i];
   }
   __syncthreads();
+  IKF_TSTAMP(1)
   IKF_FRAG(fa0, fb0, 0, 0)
 
+  using S0_ = std::integral_constant<int, 0>;
+  using S1_ = std::integral_constant<int, 1>;
+  // iteration kt stores tile kt+1 from set (kt+1)&1 and refills that set with tile kt+3
   int cur = 0, kt = 0;
-  for (; kt + 2 < KT; ++kt) {
+  for (; kt + 4 < KT; kt += 2) {
+    int nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
+    cur = nxt;
+    nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, T_{}, S0_{}, kt + 1, cur, nxt);
+    cur = nxt;
+#ifdef IKF_TRACE
+    if ((kt & 3) == 2 && kt < 128) IKF_TSTAMP(2 + (kt >> 2))
+#endif
+  }
+  for (; kt < KT; ++kt) {  // last (up to 4) tiles: no tile kt+3 to fetch, possibly no tile kt+1 to stage
     const int nxt = (cur == 2) ? 0 : cur + 1;
-    k_tile(T_{}, T_{}, kt, cur, nxt);
+    const bool has1 = (kt + 1 < KT), has3 = (kt + 3 < KT);
+    if (kt & 1) {
+      if (has3) k_tile(T_{}, T_{}, S0_{}, kt, cur, nxt);
+      else if (has1) k_tile(T_{}, F_{}, S0_{}, kt, cur, nxt);
+      else k_tile(F_{}, F_{}, S0_{}, kt, cur, nxt);
+    } else {
+      if (has3) k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
+      else if (has1) k_tile(T_{}, F_{}, S1_{}, kt, cur, nxt);
+      else k_tile(F_{}, F_{}, S1_{}, kt, cur, nxt);
+    }
     cur = nxt;
   }
-  if (kt + 1 < KT) {
-    const int nxt = (cur == 2) ? 0 : cur + 1;
-    k_tile(T_{}, F_{}, kt, cur, nxt);
-    cur = nxt;
-    ++kt;
-  }
-  k_tile(F_{}, F_{}, kt, cur, cur);
+  IKF_TSTAMP(40)
 #undef IKF_GLOAD
 #undef IKF_LSTORE
 #undef IKF_FRAG
@@ -444,6 +482,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
       }
     }
   }
+  IKF_TSTAMP(41)
 }
 
 // ---------------------------------------------------------------------------------------------------------------

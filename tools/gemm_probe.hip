@@ -5,7 +5,9 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#define IKF_TRACE 1
 #include "../ikflow_amd/csrc/flow_kernels.hip"
+#include "../ikflow_amd/csrc/flow_fused.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
@@ -38,12 +40,12 @@ __global__ __launch_bounds__(512) void k_mfma_only(float* out, int n_mfma, float
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 4096;
   int iters = argc > 2 ? atoi(argv[2]) : 100;
-  const int N = 1024, K = 1024;
+  const int N = 1024; const int K = argc > 4 ? atoi(argv[4]) : 1024;
   const int Mp = (M + 127) / 128 * 128;
   std::vector<float> hA((size_t)Mp * K), hW((size_t)N * K), hb(N);
   srand(1);
   for (auto& v : hA) v = (rand() / (float)RAND_MAX) * 2.f - 1.f;
-  for (auto& v : hW) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.03125f;
+  for (auto& v : hW) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.03125f * (K > 1024 ? 0.5f : 1.f);
   for (auto& v : hb) v = ((rand() / (float)RAND_MAX) * 2.f - 1.f) * 0.03125f;
   float *A, *W, *b, *C, *R;
   CK(hipMalloc(&A, hA.size() * 4)); CK(hipMalloc(&W, hW.size() * 4)); CK(hipMalloc(&b, N * 4));
@@ -69,6 +71,62 @@ int main(int argc, char** argv) {
     }
   }
   int vsel = argc > 3 ? atoi(argv[3]) : -1;
+  if (vsel >= 100) {  // the fused-pipeline contraction (k_flow_gemm<false>, tile config vsel-100): timing + in-kernel timeline
+    ikf::FusedGemmArgs g{}; g.A = A; g.W = W; g.bias = b; g.C = C; g.M = M; g.N = N; g.K = K; g.slope = 0.01f;
+    const int cfg = vsel - 100;
+    CK(hipMemset(C, 0, (size_t)Mp * N * 4));
+    CK(ikf::launch_flow_gemm(false, cfg, g, 0)); CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0; for (size_t i = 0; i < hC.size(); ++i) maxerr = fmax(maxerr, fabs((double)hC[i] - hR[i]));
+    for (int rep = 0; rep < 3; ++rep) {
+      for (int i = 0; i < 10; ++i) ikf::launch_flow_gemm(false, cfg, g, 0);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) ikf::launch_flow_gemm(false, cfg, g, 0);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("k_flow_gemm cfg %d M=%d K=%d: %.2f us/launch  %.1f TFLOP/s  maxerr %.2e\n", cfg, M, K, 1000.0 * ms / iters, flop / (ms / iters * 1e-3) / 1e12, maxerr);
+    }
+    unsigned long long* tb; const int nb = 4096;
+    CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
+    ikf::launch_flow_gemm(false, cfg, g, 0); ikf::launch_flow_gemm(false, cfg, g, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> ht((size_t)nb * 64);
+    CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+    for (int bI : {0, 100}) {
+      const unsigned long long* r = &ht[(size_t)bI * 64];
+      printf("block %3d: prologue %llu |", bI, r[1] - r[0]);
+      unsigned long long prev = r[1];
+      for (int q = 0; q < 32 && r[2 + q]; ++q) { printf(" %llu", r[2 + q] - prev); prev = r[2 + q]; }
+      printf(" | tail-tiles %llu  epilogue %llu  total %llu cycles\n", r[40] - prev, r[41] - r[40], r[41] - r[0]);
+    }
+    unsigned long long z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &z, sizeof(z)));
+    return 0;
+  }
+  if (false) {
+    unsigned long long* tb; const int nb = ((M + 127) / 128) * (N / 128);
+    CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
+    for (int i = 0; i < 3; ++i) ikf::launch_gemm_lrelu(vsel, A, W, b, C, M, N, K, 0.01f, 0);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
+    ikf::launch_gemm_lrelu(vsel, A, W, b, C, M, N, K, 0.01f, 0);
+    ikf::launch_gemm_lrelu(vsel, A, W, b, C, M, N, K, 0.01f, 0);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> ht((size_t)nb * 64);
+    CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0min = ~0ull, tendmax = 0;
+    for (int bI = 0; bI < nb; ++bI) { if (ht[bI*64] < t0min) t0min = ht[bI*64]; if (ht[bI*64+41] > tendmax) tendmax = ht[bI*64+41]; }
+    printf("trace (cycles of s_memtime clock): kernel span first-start..last-end = %llu\n", tendmax - t0min);
+    for (int bI : {0, 100}) {
+      if (bI >= nb) continue;
+      const unsigned long long* r = &ht[(size_t)bI * 64];
+      printf("block %3d: start+%llu  prologue %llu |", bI, r[0] - t0min, r[1] - r[0]);
+      unsigned long long prev = r[1];
+      for (int q = 0; q < 32 && r[2 + q]; ++q) { printf(" %llu", r[2 + q] - prev); prev = r[2 + q]; }
+      printf(" | tail-tiles %llu  epilogue %llu  end+%llu\n", r[40] - prev, r[41] - r[40], tendmax - r[41]);
+    }
+    unsigned long long z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &z, sizeof(z)));
+  }
   for (int v = 0; v < ikf::gemm_variant_count(); ++v) {
     if (vsel >= 0 && v != vsel) continue;
     CK(hipMemset(C, 0, (size_t)Mp * N * 4));
