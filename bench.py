@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the CPU-baseline sample")
     p.add_argument("--gemm-variant", type=int, default=-1)
+    p.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3"],
+                   help="arithmetic of the hidden contractions: exact-f32 MFMA, or the error-compensated 3x f16 MFMA split")
     p.add_argument("--extras", action="store_true", help="also time B=512 approx and exact IK (reported under `extra`)")
     return p.parse_args()
 
@@ -130,6 +132,8 @@ def main():
     eng = solver.engine(dev)
     if args.gemm_variant >= 0:
         eng.set_gemm_variant(args.gemm_variant)
+    if args.precision != "f32":
+        solver.set_precision(args.precision)
 
     B = args.batch
     # poses = FK(q), q ~ U(lo+eps, hi-eps), numpy default_rng(seed); latents N(0,1)

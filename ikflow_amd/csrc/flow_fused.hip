@@ -175,7 +175,21 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
       acc.z = acc.z > 0.f ? acc.z : acc.z * e.slope;
       acc.w = acc.w > 0.f ? acc.w : acc.w * e.slope;
       // h rows are padded to a multiple of 128 (engine scratch): unpredicated
-      reinterpret_cast<floatx4*>(e.h_out + (size_t)(m0 + r) * e.width)[c4] = acc;
+      if (!e.split_out) {
+        reinterpret_cast<floatx4*>(e.h_out + (size_t)(m0 + r) * e.width)[c4] = acc;
+      } else {
+        // split-32 image: 4 consecutive columns -> 4 hi halves (8 B) and 4 lo halves (8 B, 64 B further on)
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        half4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          hi[q] = (_Float16)acc[q];
+          lo[q] = (_Float16)((acc[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
+        }
+        char* rowp = reinterpret_cast<char*>(e.h_out) + (size_t)(m0 + r) * e.width * 4 + (size_t)(c4 >> 3) * 128 + (c4 & 7) * 8;
+        *reinterpret_cast<half4*>(rowp) = hi;
+        *reinterpret_cast<half4*>(rowp + 64) = lo;
+      }
     }
   }
 }

@@ -1,0 +1,329 @@
+// Hidden Linear + LeakyReLU on the f16 matrix cores with an error-compensated operand split (gfx950).
+//
+//   a = hi + lo/2048,  hi = f16(a),  lo = f16((a - hi)*2048)    (activations split by the producing kernel's epilogue,
+//                                                               weights split once at load time)
+//   sum_k a_k w_k ~= sum hi_a hi_w  +  (sum hi_a lo_w + sum lo_a hi_w) / 2048
+//
+// i.e. three v_mfma_f32_32x32x16_f16 (fp32 accumulate) instead of eight v_mfma_f32_32x32x2_f32 per 16 k: 5.3x less
+// matrix-pipe time.  The dropped lo*lo term is 2^-22 relative; on hardware the split result is CLOSER to fp64 than the
+// exact-f32 MFMA chain (rms 1.5e-7 vs 4.1e-7 at K = 1024, tools/split_probe.hip) because each MFMA folds 16 products
+// into the accumulator with one rounding.  Range: |activation| must stay below 65504 (f16); hidden activations of
+// the IKFlow subnets are O(1..100).
+//
+// Same role, tile and pipeline as k_flow_gemm (flow_fused.hip): 128x128 tile, 4 waves of 64x64, 3 LDS stages of 32 k,
+// one barrier per stage placed mid-stage, global loads two stages ahead.  A stage row is the 128-byte split-32 line
+// [32 hi | 32 lo] (+16 B pad -> conflict-free ds_read_b128); a fragment read of 16 B = 8 halves = one MFMA operand.
+#include <type_traits>
+
+#include "ikf_internal.h"
+
+namespace ikf {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+constexpr int SBM = 128, SBN = 128, SWAVES_M = 2, SWAVES_N = 2;
+constexpr int SNT = SWAVES_M * SWAVES_N * 64;
+
+template <bool EPI_RED>
+__global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
+  constexpr int BM = SBM, BN = SBN, NT = SNT;
+  constexpr int WM = BM / SWAVES_M, WN = BN / SWAVES_N;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int LDK = 36;            // dwords per stage row: 128 B line + 16 B pad
+  constexpr int KQ = 8;              // 16-byte slots per line: 0..3 hi (k 0-7, 8-15, 16-23, 24-31), 4..7 lo
+  constexpr int A_F4 = BM * KQ / NT;
+  constexpr int B_F4 = BN * KQ / NT;
+  constexpr int RS = NT / KQ;
+  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int LDT = BN + 4;
+  static_assert(3 * STAGE >= (BM + 32) * LDT, "epilogue tile must fit in the stage area");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][LDK]
+
+  const int M = g.M, N = g.N, K = g.K;
+  const int tiles_n = N / BN;
+  const int nwg = gridDim.x;
+  int tile;
+  {
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+  }
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = (wave / SWAVES_N) * WM, wn = (wave % SWAVES_N) * WN;
+
+  floatx16 am[MI][NI], ac[MI][NI];  // hi*hi sums, (hi*lo + lo*hi) sums
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac[i][j][r] = 0.f; }
+
+  const int row_t = t / KQ, kq_t = (t % KQ) * 4;  // dword offset of this thread's 16-B slot in a line
+  const float* Af = reinterpret_cast<const float*>(g.A);
+  const float* Wf = reinterpret_cast<const float*>(g.W);
+  const float* a_src[A_F4];
+#pragma unroll
+  for (int i = 0; i < A_F4; ++i) {
+    int gr = m0 + row_t + i * RS;
+    gr = gr < M ? gr : M - 1;
+    a_src[i] = Af + (size_t)gr * K + kq_t;  // a split-32 row is K dwords long; K tile kt starts at dword 32*kt
+  }
+  const float* b_base = Wf + (size_t)(n0 + row_t) * K + kq_t;
+  const int lds_t = row_t * LDK + kq_t;
+  // fragment of k16-step s, plane p (0 hi, 1 lo): slot p*4 + s*2 + (lane>>5)
+  const int fragA = (wm + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int fragB = BM * LDK + (wn + (lane & 31)) * LDK + (lane >> 5) * 4;
+  const int KT = K / 32;
+
+  floatx4 ra[2][A_F4], rb[2][B_F4];
+  half8 ah0[MI], al0[MI], bh0[NI], bl0[NI], ah1[MI], al1[MI], bh1[NI], bl1[NI];
+
+#define IKS_GLOAD(S, kt_)                                                                                          \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[S][i] = *reinterpret_cast<const floatx4*>(a_src[i] + (kt_) * 32); \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
+        rb[S][i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (kt_) * 32);                 \
+  }
+#define IKS_LSTORE(S, stage)                                                                                      \
+  {                                                                                                               \
+    float* sp_ = smem + (stage) * STAGE + lds_t;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp_ + i * RS * LDK) = ra[S][i];   \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
+        *reinterpret_cast<floatx4*>(sp_ + BM * LDK + i * RS * LDK) = rb[S][i];                                    \
+  }
+#define IKS_FRAG(AH, AL, BH, BL, stage, s_)                                                                        \
+  {                                                                                                               \
+    const float* sp_ = smem + (stage) * STAGE + (s_) * 8;                                                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
+      AH[i] = *reinterpret_cast<const half8*>(sp_ + fragA + i * 32 * LDK);                                        \
+      AL[i] = *reinterpret_cast<const half8*>(sp_ + fragA + i * 32 * LDK + 16);                                   \
+    }                                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                              \
+      BH[j] = *reinterpret_cast<const half8*>(sp_ + fragB + j * 32 * LDK);                                        \
+      BL[j] = *reinterpret_cast<const half8*>(sp_ + fragB + j * 32 * LDK + 16);                                   \
+    }                                                                                                             \
+  }
+#define IKS_MFMA3(AH, AL, BH, BL)                                                                                  \
+  {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)                  \
+      am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], am[i][j], 0, 0, 0);                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)                  \
+      ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], ac[i][j], 0, 0, 0);                         \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)                  \
+      ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], ac[i][j], 0, 0, 0);                         \
+  }
+
+  // One stage (32 k = two k16-steps). Step 0 fragments are already in set 0; step 0's MFMAs shadow the LDS write of
+  // tile kt+1, the global loads of tile kt+3 and the fragment reads of step 1; after the barrier step 1's MFMAs shadow
+  // the fragment reads of the next stage's step 0.
+  auto k_tile = [&](auto has1_c, auto has3_c, auto set_c, int kt, int cur, int nxt) {
+    constexpr bool HAS1 = decltype(has1_c)::value, HAS3 = decltype(has3_c)::value;
+    constexpr int S = decltype(set_c)::value;
+    IKS_FRAG(ah1, al1, bh1, bl1, cur, 1)
+    IKS_MFMA3(ah0, al0, bh0, bl0)
+    if (HAS1) IKS_LSTORE(S, nxt)
+    if (HAS3) IKS_GLOAD(S, kt + 3)
+    {
+      constexpr int n_mfma = MI * NI * 3;
+      constexpr int n_rd = 2 * (MI + NI), n_wr = HAS1 ? A_F4 + B_F4 : 0, n_ld = HAS3 ? A_F4 + B_F4 : 0;
+      // 12 MFMAs, 8 reads, 8 writes, 8 loads: reads first (needed right after the barrier), then writes, then loads
+#pragma unroll
+      for (int i = 0; i < n_mfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, n_rd / 4, 0);
+        else if (i < 8) __builtin_amdgcn_sched_group_barrier(0x200, (n_wr + 3) / 4, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x020, (n_ld + 3) / 4, 0);
+      }
+    }
+    __syncthreads();
+    if (HAS1) IKS_FRAG(ah0, al0, bh0, bl0, nxt, 0)
+    IKS_MFMA3(ah1, al1, bh1, bl1)
+    {
+      constexpr int n_mfma = MI * NI * 3;
+      constexpr int n_rd = HAS1 ? 2 * (MI + NI) : 0;
+#pragma unroll
+      for (int i = 0; i < n_mfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (i < 8 && n_rd > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_rd / 8, 0);
+      }
+    }
+  };
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+  using S0_ = std::integral_constant<int, 0>;
+  using S1_ = std::integral_constant<int, 1>;
+
+  {
+    floatx4 ra0[A_F4], rb0[B_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) ra0[i] = *reinterpret_cast<const floatx4*>(a_src[i]);
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) rb0[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K);
+    if (KT > 1) IKS_GLOAD(1, 1)
+    if (KT > 2) IKS_GLOAD(0, 2)
+    float* sp0 = smem + lds_t;
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + i * RS * LDK) = ra0[i];
+#pragma unroll
+    for (int i = 0; i < B_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + BM * LDK + i * RS * LDK) = rb0[i];
+  }
+  __syncthreads();
+  IKS_FRAG(ah0, al0, bh0, bl0, 0, 0)
+
+  int cur = 0, kt = 0;
+  for (; kt + 4 < KT; kt += 2) {
+    int nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
+    cur = nxt;
+    nxt = (cur == 2) ? 0 : cur + 1;
+    k_tile(T_{}, T_{}, S0_{}, kt + 1, cur, nxt);
+    cur = nxt;
+  }
+  for (; kt < KT; ++kt) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    const bool has1 = (kt + 1 < KT), has3 = (kt + 3 < KT);
+    if (kt & 1) {
+      if (has3) k_tile(T_{}, T_{}, S0_{}, kt, cur, nxt);
+      else if (has1) k_tile(T_{}, F_{}, S0_{}, kt, cur, nxt);
+      else k_tile(F_{}, F_{}, S0_{}, kt, cur, nxt);
+    } else {
+      if (has3) k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
+      else if (has1) k_tile(T_{}, F_{}, S1_{}, kt, cur, nxt);
+      else k_tile(F_{}, F_{}, S1_{}, kt, cur, nxt);
+    }
+    cur = nxt;
+  }
+#undef IKS_GLOAD
+#undef IKS_LSTORE
+#undef IKS_FRAG
+#undef IKS_MFMA3
+
+  // ---- epilogue: v = hi*hi + corr/2048 + bias, LeakyReLU, into the LDS tile T[BM][LDT] (fp32)
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  __syncthreads();  // every wave is done reading the last stage
+  float* T = smem;
+  constexpr float inv_scale = 1.0f / IKF_SPLIT_SCALE;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int cl = wn + j * 32 + col_l;
+    const float bv = g.bias[n0 + cl];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
+        float v = fmaf(ac[i][j][r], inv_scale, am[i][j][r]) + bv;
+        v = v > 0.f ? v : v * g.slope;
+        T[rl * LDT + cl] = v;
+      }
+    }
+  }
+  if constexpr (!EPI_RED) {
+    // re-split and store the tile as split-32 lines: a thread converts 8 consecutive columns -> 8 hi (16 B) + 8 lo (16 B)
+    __syncthreads();
+    char* Cb = reinterpret_cast<char*>(g.C);
+    constexpr int CH = BN / 8;  // 8-column chunks per row
+    for (int idx = t; idx < BM * CH; idx += NT) {
+      const int rl = idx / CH, ch = idx - rl * CH;
+      const floatx4 v0 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8);
+      const floatx4 v1 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8 + 4);
+      half8 hi, lo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hi[q] = (_Float16)v0[q];
+        lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
+        hi[4 + q] = (_Float16)v1[q];
+        lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
+      }
+      const int col = n0 + ch * 8;  // global column of the chunk; block of 32 columns = one 128-B line
+      char* p = Cb + (size_t)(m0 + rl) * N * 4 + (size_t)(col >> 5) * 128 + (col & 31) * 2;
+      *reinterpret_cast<half8*>(p) = hi;
+      *reinterpret_cast<half8*>(p + 64) = lo;
+    }
+  } else {
+    // last Linear restricted to this tile's columns, in exact f32 MFMA (identical to k_flow_gemm<true>): one slot per 64 columns
+    float* Wl = smem + BM * LDT;
+    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
+      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
+    }
+    __syncthreads();
+    constexpr int RB = BM / 32, FKH = BN / 64, CW = 64;
+    for (int job = wave; job < RB * FKH; job += NT / 64) {  // 8 (row block, column half) jobs over 4 waves
+      const int rb = job % RB, kh = job / RB;
+      floatx16 pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      const float* pa = Wl + (lane & 31) * LDT + kh * CW + (lane >> 5) * 4;
+      const float* pb = T + (rb * 32 + (lane & 31)) * LDT + kh * CW + (lane >> 5) * 4;
+#pragma unroll
+      for (int ks = 0; ks < CW / 8; ++ks) {
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+      }
+      float* pout = g.P_out + (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + row_h;
+        pout[o] = pacc[r];
+      }
+    }
+  }
+}
+
+const char* split_kernel_name() { return "k_split_gemm"; }
+
+template <bool EPI_RED>
+static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)3 * (SBM + SBN) * 36 * sizeof(float);
+  auto kern = k_split_gemm<EPI_RED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long long tiles_m = ((long long)a.M + SBM - 1) / SBM;
+  const long long grid = tiles_m * (a.N / SBN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SNT), smem, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_split_gemm(bool epi_red, const SplitGemmArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (a.N % SBN != 0 || a.K % 32 != 0 || a.n_out > 16) return hipErrorInvalidValue;
+  return epi_red ? launch_sg<true>(a, s) : launch_sg<false>(a, s);
+}
+
+// host: fp32 [rows][K] -> split-32 image (rows * K * 2 uint16 = rows * K * 4 bytes)
+void split32_pack_host(const float* src, int rows, int K, uint16_t* dst) {
+  for (int r = 0; r < rows; ++r) {
+    const float* sr = src + (size_t)r * K;
+    uint16_t* dr = dst + (size_t)r * K * 2;
+    for (int k = 0; k < K; ++k) {
+      const _Float16 hi = (_Float16)sr[k];
+      const _Float16 lo = (_Float16)((sr[k] - (float)hi) * IKF_SPLIT_SCALE);
+      uint16_t hb, lb;
+      __builtin_memcpy(&hb, &hi, 2);
+      __builtin_memcpy(&lb, &lo, 2);
+      dr[(size_t)(k >> 5) * 64 + (k & 31)] = hb;
+      dr[(size_t)(k >> 5) * 64 + 32 + (k & 31)] = lb;
+    }
+  }
+}
+
+}  // namespace ikf

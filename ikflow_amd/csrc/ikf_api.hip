@@ -33,6 +33,9 @@ struct ikf_model {
   bool loaded = false;
   int gemm_variant = -1;  // -1 = choose by batch size
   int tile_cfg = -1;      // fused pipeline: -1 = choose by batch size, 0..3 forced (variant 100..103)
+  int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
+  uint16_t* split_arena = nullptr;  // split-32 images of the hidden Linear weights
+  std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
 
   // packed weights (one arena)
   float* arena = nullptr;
@@ -82,6 +85,7 @@ static const long long kMaxChunkRows = 16384;  // keeps the [chunk x width] acti
 extern "C" const char* ikf_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ikf_abi_version(void) { return IKF_ABI_VERSION; }
 extern "C" const char* ikf_dominant_kernel_name(void) { return fused_kernel_name(); }
+extern "C" const char* ikf_split_kernel_name(void) { return split_kernel_name(); }
 
 static void free_scratch(ikf_model* m) {
   if (m->xbuf) (void)hipFree(m->xbuf);
@@ -164,6 +168,7 @@ extern "C" void ikf_destroy(ikf_model* m) {
   free_scratch(m);
   free_exact(m);
   if (m->arena) (void)hipFree(m->arena);
+  if (m->split_arena) (void)hipFree(m->split_arena);
   if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
   if (m->d_Minv) (void)hipFree(m->d_Minv);
   if (m->d_blin) (void)hipFree(m->d_blin);
@@ -335,6 +340,22 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
     s.b_last = m->arena + off_blast[si];
   }
   m->subnets = subs;
+  // split-32 images of the hidden Linear weights for the f16-split contraction (same bytes as fp32)
+  if (m->split_arena) { (void)hipFree(m->split_arena); m->split_arena = nullptr; }
+  m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
+  if (d.n_hidden >= 2 && W % 128 == 0) {
+    const size_t per = (size_t)W * W * 2;  // uint16 elements per layer
+    const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
+    std::vector<uint16_t> hs(per * n_layers);
+    size_t li = 0;
+    for (int si = 0; si < 2 * NB; ++si)
+      for (int l = 0; l < d.n_hidden - 1; ++l, ++li) split32_pack_host(&host[off_mid[si][l]], W, W, &hs[li * per]);
+    IKF_HIP(hipMalloc(&m->split_arena, sizeof(uint16_t) * per * n_layers));
+    IKF_HIP(hipMemcpy(m->split_arena, hs.data(), sizeof(uint16_t) * per * n_layers, hipMemcpyHostToDevice));
+    li = 0;
+    for (int si = 0; si < 2 * NB; ++si)
+      for (int l = 0; l < d.n_hidden - 1; ++l, ++li) m->w_mid_split[(size_t)si * 3 + l] = m->split_arena + li * per;
+  }
   m->loaded = true;
   return IKF_OK;
 }
@@ -444,7 +465,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     e.x_off = (which == 1) ? 0 : d.L1; e.n_x = w.n_x;
     e.ps = ps; e.row0 = r0;
     e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
-    e.width = d.width; e.slope = d.slope; e.h_out = m->hA;
+    const bool split = (m->precision == 1) && m->split_arena != nullptr;
+    e.width = d.width; e.slope = d.slope; e.h_out = m->hA; e.split_out = split ? 1 : 0;
     IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     FusedGemmArgs g{};
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
@@ -454,9 +476,17 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     float* nxt = m->hB;
     for (int l = 0; l < n_mid; ++l) {
       const bool last = (l == n_mid - 1);
-      g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
       IKF_HIP(prof_mark(m, s));
-      IKF_HIP(launch_flow_gemm(last, cfg, g, s));
+      if (split) {
+        SplitGemmArgs sg{};
+        sg.A = cur; sg.C = last ? nullptr : nxt; sg.W = m->w_mid_split[(size_t)(2 * b + which - 1) * 3 + l];
+        sg.bias = w.b_mid[l]; sg.M = (int)nr; sg.N = d.width; sg.K = d.width; sg.slope = d.slope;
+        sg.w_last = w.w_last; sg.n_out = w.n_out; sg.P_out = m->pbuf; sg.p_slot_stride = rows_pad * IKF_PSTRIDE;
+        IKF_HIP(launch_split_gemm(last, sg, s));
+      } else {
+        g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
+        IKF_HIP(launch_flow_gemm(last, cfg, g, s));
+      }
       IKF_HIP(prof_mark(m, s));
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
@@ -735,3 +765,13 @@ extern "C" ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double*
   m->prof_used = 0;
   return IKF_OK;
 }
+
+extern "C" ikf_status ikf_set_precision(ikf_model* m, int mode) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_precision: null model");
+  if (mode != 0 && mode != 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_precision: mode must be 0 (f32 MFMA) or 1 (3x f16 split)");
+  if (mode == 1 && (m->dims.n_hidden < 2 || m->dims.width % 128 != 0))
+    return fail(IKF_ERR_BAD_SHAPE, "ikf_set_precision: the f16-split contraction needs a width that is a multiple of 128 and >= 2 hidden layers");
+  m->precision = mode;
+  return IKF_OK;
+}
+extern "C" int ikf_get_precision(const ikf_model* m) { return m ? m->precision : -1; }

@@ -85,7 +85,8 @@ struct EntryArgs {      // k_subnet_entry: pending coupling + first Linear of th
   const float* b1;      // [width]
   int width;
   float slope;
-  float* h_out;         // [rows_pad][width]
+  float* h_out;         // [rows_pad][width]  fp32, or the f16 hi/lo split image when split_out != 0
+  int split_out;
 };
 struct FusedGemmArgs {
   // contraction C = lrelu(A . W^T + bias), K = N = width
@@ -120,6 +121,29 @@ hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s);
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s);
 hipError_t launch_flow_finalize(const FinalizeArgs& a, hipStream_t s);
 const char* fused_kernel_name();
+
+// flow_split.hip - the hidden contraction on the f16 matrix cores with an error-compensated operand split:
+//   a = hi + lo/2048,  hi = f16(a),  lo = f16((a - hi) * 2048)        (same for the weights, split once at load)
+//   a.w ~= hi_a*hi_w + (hi_a*lo_w + lo_a*hi_w)/2048                    (3 v_mfma_f32_32x32x16_f16, fp32 accumulate)
+// Measured on MI355X against fp64 (tools/split_probe.hip): rms error 1.5e-7 vs 4.1e-7 for the exact-f32 MFMA at K=1024.
+// Operands live in HBM as the "split-32" image: per row, per block of 32 k: 32 hi halves (64 B) then 32 lo halves (64 B)
+// - 4 bytes per element like fp32, one full 128-B line per (row, K tile).
+constexpr float IKF_SPLIT_SCALE = 2048.0f;
+struct SplitGemmArgs {
+  const void* A;      // [rows_pad][K] split-32 image
+  const void* W;      // [N][K] split-32 image
+  const float* bias;  // [N]
+  void* C;            // [rows_pad][N] split-32 image (unused when the epilogue reduces to partials)
+  int M, N, K;
+  float slope;
+  const float* w_last;  // [n_out][N] fp32
+  int n_out;
+  float* P_out;
+  long long p_slot_stride;
+};
+hipError_t launch_split_gemm(bool epi_red, const SplitGemmArgs& a, hipStream_t s);
+void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // host-side packer for the weights
+const char* split_kernel_name();
 
 // kin_kernels.hip
 struct Chain {

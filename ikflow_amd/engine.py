@@ -157,6 +157,16 @@ class Engine:
     def reserve(self, max_rows: int) -> None:
         _check(self.lib.ikf_reserve(self._h, int(max_rows)))
 
+    PRECISIONS = {"f32": 0, "f16x3": 1}
+
+    def set_precision(self, mode: str) -> None:
+        """"f32": hidden contractions on the exact-f32 MFMA. "f16x3": error-compensated three-product f16 split."""
+        _check(self.lib.ikf_set_precision(self._h, self.PRECISIONS[mode]))
+
+    @property
+    def precision(self) -> str:
+        return {v: k for k, v in self.PRECISIONS.items()}[self.lib.ikf_get_precision(self._h)]
+
     def set_gemm_variant(self, variant: int) -> None:
         _check(self.lib.ikf_set_gemm_variant(self._h, int(variant)))
 
@@ -311,6 +321,8 @@ class Engine:
         return int(n.value), float(ms.value)
 
     def dominant_kernel_name(self) -> str:
+        if self.precision == "f16x3":
+            return self.lib.ikf_split_kernel_name().decode()
         return self.lib.ikf_dominant_kernel_name().decode()
 
 

@@ -77,6 +77,7 @@ class IKFlowSolver:
             warnings.warn("compile_model is ignored: the MI355X engine runs hand-written HIP kernels, nothing is traced.")
         self._model_weights_loaded = False
         self._engine = None  # created on first use, on the device of the inputs
+        self._precision = "f32"
         self._state_dict_np: Optional[Dict[str, np.ndarray]] = None
         self.ndof = self.robot.ndof
 
@@ -107,8 +108,18 @@ class IKFlowSolver:
             eng = Engine(self._layout, self._robot, device)
             if self._state_dict_np is not None:
                 eng.load_state_dict(self._state_dict_np)
+            if self._precision != "f32":
+                eng.set_precision(self._precision)
             self._engine = eng
         return self._engine
+
+    def set_precision(self, mode: str):
+        """Arithmetic of the hidden Linear contractions: "f32" (exact f32 MFMA, default) or "f16x3" (error-compensated
+        f16 split, measured at least as accurate against fp64; see include/ikflow_amd.h ikf_set_precision)."""
+        assert mode in ("f32", "f16x3"), mode
+        self._precision = mode
+        if self._engine is not None:
+            self._engine.set_precision(mode)
 
     def _ensure_initialized(self, allow_uninitialized: bool):
         """The reference runs its randomly initialised nn_model when allow_uninitialized=True

@@ -148,6 +148,14 @@ ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float* ms_out, v
  * on extra steps, not inside a throughput-timed region. */
 ikf_status ikf_profile_begin(ikf_model* m);
 ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream);
+/* Arithmetic of the hidden Linear contractions (99 % of the FLOPs):
+ *   0 = exact f32 on v_mfma_f32_32x32x2_f32 (default);
+ *   1 = error-compensated f16 split on v_mfma_f32_32x32x16_f16 (a = hi + lo/2048 for both operands, three products,
+ *       fp32 accumulate): measured closer to fp64 than mode 0 (tools/split_probe.hip), ~5x less matrix-pipe time;
+ *       hidden activations must stay below 65504 in magnitude. Everything else stays fp32 in both modes. */
+ikf_status ikf_set_precision(ikf_model* m, int mode);
+int ikf_get_precision(const ikf_model* m);
+const char* ikf_split_kernel_name(void);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
 const char* ikf_dominant_kernel_name(void);
 /* Select the flow pipeline: -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly,

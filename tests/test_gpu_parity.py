@@ -73,6 +73,35 @@ def test_flow_panda_trained_like_gain():
     assert e64 <= max(2e-5, 4 * o64)
 
 
+@pytest.mark.parametrize("which,n", [("panda", 500), ("panda", 4096), ("tiny", 300), ("fetch_arm", 200)])
+def test_flow_f16_split_precision_matches_oracle(which, n):
+    """precision="f16x3": hidden contractions as three f16 MFMA products of error-compensated hi/lo operands.
+    Same 1e-5 tolerance against the PyTorch-CPU oracle, and no further from the fp64 twin than the exact-f32 path is."""
+    model = {"panda": panda_model, "tiny": tiny_model, "fetch_arm": fetch_arm_model}[which]()
+    robot, hp, lay, sd = model
+    _, poses = reachable_poses(robot, n, 11)
+    lat = latents(n, lay.dim, 12)
+    m = min(n, 512)  # oracle on a slice for the big batch
+    ref32 = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:m], lat[:m], clamp=False)
+    cond = torch.cat([poses[:m], torch.zeros(m, 1)], 1).numpy()
+    ref64 = fo.run_inference_f64(sd, lay, robot.actuated_joints_limits, lat[:m].numpy(), cond, False)
+    s = _solver(robot, hp, sd)
+    got32 = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()[:m]
+    s.set_precision("f16x3")
+    assert s.engine(DEV).precision == "f16x3"
+    got16 = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()[:m]
+    scale = np.maximum(1.0, np.abs(ref64))
+    e16_64 = (np.abs(got16.numpy() - ref64) / scale).max()
+    e32_64 = (np.abs(got32.numpy() - ref64) / scale).max()
+    e16_cpu = ((got16 - ref32).abs().numpy() / scale).max()
+    print(f"{which} n={n}: |f16x3 - f64| {e16_64:.3e}   |f32mfma - f64| {e32_64:.3e}   |f16x3 - cpu32| {e16_cpu:.3e}")
+    assert e16_cpu <= FLOW_TOL and e16_64 <= FLOW_TOL
+    assert e16_64 <= 1.5 * e32_64 + 5e-7
+    clamped = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV)).cpu()[:m]
+    ref_cl = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:m], lat[:m], clamp=True)
+    assert (clamped - ref_cl).abs().max().item() <= FLOW_TOL
+
+
 def test_flow_fetch_arm_matches_oracle():
     got, ref32, ref64 = _flow_case(fetch_arm_model(), 200)
     assert (got - ref32).abs().max().item() <= FLOW_TOL
