@@ -23,6 +23,13 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifdef IKF_TRACE
+extern __device__ unsigned long long* ikf_trace_buf;  // defined in flow_fused.hip (probe build)
+#define IKS_TSTAMP(i) if (threadIdx.x == 0 && ikf_trace_buf) ikf_trace_buf[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+#else
+#define IKS_TSTAMP(i)
+#endif
+
 constexpr int SBM = 128, SBN = 128, SWAVES_M = 2, SWAVES_N = 2;
 constexpr int SNT = SWAVES_M * SWAVES_N * 64;
 
@@ -160,6 +167,7 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
   using S0_ = std::integral_constant<int, 0>;
   using S1_ = std::integral_constant<int, 1>;
 
+  IKS_TSTAMP(0)
   {
     floatx4 ra0[A_F4], rb0[B_F4];
 #pragma unroll
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
     for (int i = 0; i < B_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + BM * LDK + i * RS * LDK) = rb0[i];
   }
   __syncthreads();
+  IKS_TSTAMP(1)
   IKS_FRAG(ah0, al0, bh0, bl0, 0, 0)
 
   int cur = 0, kt = 0;
@@ -185,6 +194,9 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
     nxt = (cur == 2) ? 0 : cur + 1;
     k_tile(T_{}, T_{}, S0_{}, kt + 1, cur, nxt);
     cur = nxt;
+#ifdef IKF_TRACE
+    if ((kt & 3) == 2 && kt < 128) IKS_TSTAMP(2 + (kt >> 2))
+#endif
   }
   for (; kt < KT; ++kt) {
     const int nxt = (cur == 2) ? 0 : cur + 1;
@@ -200,6 +212,7 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
     }
     cur = nxt;
   }
+  IKS_TSTAMP(40)
 #undef IKS_GLOAD
 #undef IKS_LSTORE
 #undef IKS_FRAG
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
       }
     }
   }
+  IKS_TSTAMP(41)
 }
 
 const char* split_kernel_name() { return "k_split_gemm"; }
