@@ -30,7 +30,11 @@ extern __device__ unsigned long long* ikf_trace_buf;  // defined in flow_fused.h
 #define IKS_TSTAMP(i)
 #endif
 
-constexpr int SBM = 128, SBN = 128, SWAVES_M = 2, SWAVES_N = 2;
+constexpr int SBM = 128, SBN = 128, SWAVES_M = 2;
+#ifndef IKF_SPLIT_WAVES_N
+#define IKF_SPLIT_WAVES_N 2
+#endif
+constexpr int SWAVES_N = IKF_SPLIT_WAVES_N;  // 2: 4 waves of 64x64 (1 per SIMD); 4: 8 waves of 64x32 (2 per SIMD)
 constexpr int SNT = SWAVES_M * SWAVES_N * 64;
 
 template <bool EPI_RED>
@@ -144,9 +148,10 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
 #pragma unroll
       for (int i = 0; i < n_mfma; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, n_rd / 4, 0);
-        else if (i < 8) __builtin_amdgcn_sched_group_barrier(0x200, (n_wr + 3) / 4, 0);
-        else __builtin_amdgcn_sched_group_barrier(0x020, (n_ld + 3) / 4, 0);
+        constexpr int third = n_mfma / 3 > 0 ? n_mfma / 3 : 1;
+        if (i < third) __builtin_amdgcn_sched_group_barrier(0x100, (n_rd + third - 1) / third, 0);
+        else if (i < 2 * third) { if (n_wr > 0) __builtin_amdgcn_sched_group_barrier(0x200, (n_wr + third - 1) / third, 0); }
+        else { if (n_ld > 0) __builtin_amdgcn_sched_group_barrier(0x020, (n_ld + third - 1) / third, 0); }
       }
     }
     __syncthreads();
@@ -158,7 +163,8 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
 #pragma unroll
       for (int i = 0; i < n_mfma; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i < 8 && n_rd > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_rd / 8, 0);
+        constexpr int span = (2 * n_mfma) / 3 > 0 ? (2 * n_mfma) / 3 : 1;
+        if (i < span && n_rd > 0) __builtin_amdgcn_sched_group_barrier(0x100, (n_rd + span - 1) / span, 0);
       }
     }
   };
@@ -323,7 +329,39 @@ hipError_t launch_split_gemm(bool epi_red, const SplitGemmArgs& a, hipStream_t s
   return epi_red ? launch_sg<true>(a, s) : launch_sg<false>(a, s);
 }
 
-// host: fp32 [rows][K] -> split-32 image (rows * K * 2 uint16 = rows * K * 4 bytes)
+// device: fp32 [rows][K] -> split-32 image; one thread converts 8 consecutive k of a row
+__global__ __launch_bounds__(256) void k_split32_pack(const float* __restrict__ src, long long n_chunks, int K,
+                                                      char* __restrict__ dst) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_chunks) return;
+  const int cpr = K / 8;  // chunks per row
+  const long long row = idx / cpr;
+  const int k0 = (int)(idx - row * cpr) * 8;
+  const floatx4 v0 = *reinterpret_cast<const floatx4*>(src + row * K + k0);
+  const floatx4 v1 = *reinterpret_cast<const floatx4*>(src + row * K + k0 + 4);
+  half8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hi[q] = (_Float16)v0[q];
+    lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
+    hi[4 + q] = (_Float16)v1[q];
+    lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
+  }
+  char* p = dst + row * (long long)K * 4 + (long long)(k0 >> 5) * 128 + (k0 & 31) * 2;
+  *reinterpret_cast<half8*>(p) = hi;
+  *reinterpret_cast<half8*>(p + 64) = lo;
+}
+
+hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (K % 32 != 0) return hipErrorInvalidValue;
+  const long long n_chunks = rows * (K / 8);
+  hipLaunchKernelGGL(k_split32_pack, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, d_src, n_chunks, K,
+                     reinterpret_cast<char*>(d_dst));
+  return hipGetLastError();
+}
+
+// host: fp32 [rows][K] -> split-32 image (rows * K * 2 uint16 = rows * K * 4 bytes); used by the probes/tests only
 void split32_pack_host(const float* src, int rows, int K, uint16_t* dst) {
   for (int r = 0; r < rows; ++r) {
     const float* sr = src + (size_t)r * K;

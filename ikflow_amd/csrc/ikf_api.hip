@@ -213,6 +213,26 @@ static ikf_status need(const std::unordered_map<std::string, const ikf_tensor*>&
 
 static size_t align64(size_t n) { return (n + 63) & ~size_t(63); }  // 64 floats = 256 B
 
+// split-32 images (same bytes as fp32) of every hidden Linear weight, converted on the device from the fp32 arena
+static ikf_status build_split_weights(ikf_model* m) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes, W = d.width;
+  if (m->split_arena || d.n_hidden < 2 || W % 128 != 0 || !m->loaded) return IKF_OK;
+  const size_t per = (size_t)W * W * 2;  // uint16 elements per layer
+  const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
+  IKF_HIP(hipMalloc(&m->split_arena, sizeof(uint16_t) * per * n_layers));
+  m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
+  size_t li = 0;
+  for (int si = 0; si < 2 * NB; ++si)
+    for (int l = 0; l < d.n_hidden - 1; ++l, ++li) {
+      uint16_t* dst = m->split_arena + li * per;
+      IKF_HIP(launch_split32_pack(m->subnets[si].w_mid[l], W, W, dst, nullptr));
+      m->w_mid_split[(size_t)si * 3 + l] = dst;
+    }
+  IKF_HIP(hipDeviceSynchronize());
+  return IKF_OK;
+}
+
 extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors) {
   if (!m || !tensors) return fail(IKF_ERR_NULL_POINTER, "ikf_load_weights: null argument");
   IKF_HIP(hipSetDevice(m->device));
@@ -340,21 +360,13 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
     s.b_last = m->arena + off_blast[si];
   }
   m->subnets = subs;
-  // split-32 images of the hidden Linear weights for the f16-split contraction (same bytes as fp32)
+  // the split-32 weight images of the f16-split contraction are built on the device when that mode is selected
   if (m->split_arena) { (void)hipFree(m->split_arena); m->split_arena = nullptr; }
   m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
-  if (d.n_hidden >= 2 && W % 128 == 0) {
-    const size_t per = (size_t)W * W * 2;  // uint16 elements per layer
-    const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
-    std::vector<uint16_t> hs(per * n_layers);
-    size_t li = 0;
-    for (int si = 0; si < 2 * NB; ++si)
-      for (int l = 0; l < d.n_hidden - 1; ++l, ++li) split32_pack_host(&host[off_mid[si][l]], W, W, &hs[li * per]);
-    IKF_HIP(hipMalloc(&m->split_arena, sizeof(uint16_t) * per * n_layers));
-    IKF_HIP(hipMemcpy(m->split_arena, hs.data(), sizeof(uint16_t) * per * n_layers, hipMemcpyHostToDevice));
-    li = 0;
-    for (int si = 0; si < 2 * NB; ++si)
-      for (int l = 0; l < d.n_hidden - 1; ++l, ++li) m->w_mid_split[(size_t)si * 3 + l] = m->split_arena + li * per;
+  m->loaded = true;
+  if (m->precision == 1) {
+    ikf_status sst = build_split_weights(m);
+    if (sst != IKF_OK) return sst;
   }
   m->loaded = true;
   return IKF_OK;
@@ -772,6 +784,10 @@ extern "C" ikf_status ikf_set_precision(ikf_model* m, int mode) {
   if (mode == 1 && (m->dims.n_hidden < 2 || m->dims.width % 128 != 0))
     return fail(IKF_ERR_BAD_SHAPE, "ikf_set_precision: the f16-split contraction needs a width that is a multiple of 128 and >= 2 hidden layers");
   m->precision = mode;
+  if (mode == 1) {
+    IKF_HIP(hipSetDevice(m->device));
+    return build_split_weights(m);
+  }
   return IKF_OK;
 }
 extern "C" int ikf_get_precision(const ikf_model* m) { return m ? m->precision : -1; }
