@@ -251,7 +251,9 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                      "traffic_source": traffic_src, "kernel": eng.dominant_kernel_name(),
-                     "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms},
+                     "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms,
+                     "timing": f"hipEvent pair per launch on the engine stream, {n_launch} launches over extra steps; an empty pair "
+                               f"({eng.last_event_overhead_ms * 1e3:.2f} us, calibrated on the same stream) is subtracted"},
         "extra": extra,
     }
     if rank == 0:

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ikf_time_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "ikf_profile_begin": (C.c_int, [C.c_void_p]),
     "ikf_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p]),
+    "ikf_profile_event_overhead_ms": (C.c_double, [C.c_void_p]),
     "ikf_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "ikf_get_precision": (C.c_int, [C.c_void_p]),
     "ikf_split_kernel_name": (C.c_char_p, []),

@@ -66,6 +66,7 @@ struct ikf_model {
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs
   size_t prof_used = 0;
+  double last_event_overhead_ms = 0.0;
 };
 
 static const size_t kProfMaxPairs = 8192;
@@ -763,20 +764,39 @@ extern "C" ikf_status ikf_profile_begin(ikf_model* m) {
 extern "C" ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream) {
   if (!m || !n_launches || !total_ms) return fail(IKF_ERR_NULL_POINTER, "ikf_profile_end: null argument");
   IKF_HIP(hipSetDevice(m->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
   m->prof_on = false;
-  IKF_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  // calibrate what an (otherwise empty) event pair measures on this stream and take it off every bracketed launch
+  const int ncal = 32;
+  hipEvent_t cal[2 * ncal];
+  for (int i = 0; i < 2 * ncal; ++i) IKF_HIP(hipEventCreate(&cal[i]));
+  for (int i = 0; i < ncal; ++i) {
+    IKF_HIP(hipEventRecord(cal[2 * i], s));
+    IKF_HIP(hipEventRecord(cal[2 * i + 1], s));
+  }
+  IKF_HIP(hipStreamSynchronize(s));
+  double empty = 0.0;
+  for (int i = 0; i < ncal; ++i) {
+    float ms = 0.f;
+    IKF_HIP(hipEventElapsedTime(&ms, cal[2 * i], cal[2 * i + 1]));
+    empty += ms;
+  }
+  empty /= ncal;
+  for (int i = 0; i < 2 * ncal; ++i) (void)hipEventDestroy(cal[i]);
   double tot = 0.0;
   const size_t pairs = m->prof_used / 2;
   for (size_t i = 0; i < pairs; ++i) {
     float ms = 0.f;
     IKF_HIP(hipEventElapsedTime(&ms, m->prof_ev[2 * i], m->prof_ev[2 * i + 1]));
-    tot += ms;
+    tot += (ms > empty ? ms - empty : 0.0);
   }
   *n_launches = (int64_t)pairs;
   *total_ms = tot;
   m->prof_used = 0;
+  m->last_event_overhead_ms = empty;
   return IKF_OK;
 }
+extern "C" double ikf_profile_event_overhead_ms(const ikf_model* m) { return m ? m->last_event_overhead_ms : 0.0; }
 
 extern "C" ikf_status ikf_set_precision(ikf_model* m, int mode) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_precision: null model");

@@ -318,6 +318,7 @@ class Engine:
         n, ms = C.c_int64(0), C.c_double(0.0)
         with torch.cuda.device(self.device):
             _check(self.lib.ikf_profile_end(self._h, C.byref(n), C.byref(ms), self._stream()))
+        self.last_event_overhead_ms = float(self.lib.ikf_profile_event_overhead_ms(self._h))
         return int(n.value), float(ms.value)
 
     def dominant_kernel_name(self) -> str:

@@ -144,10 +144,13 @@ ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t
 ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float* ms_out, void* stream);
 /* Per-launch timing of the dominant kernel inside real calls: between _begin and _end every hidden-Linear contraction
  * launched by ikf_generate_approx/_exact on `stream` is bracketed by a hipEvent pair; _end synchronises the stream and
- * returns the number of launches and the sum of their elapsed times (ms). Adds two event records per launch - use it
- * on extra steps, not inside a throughput-timed region. */
+ * returns the number of launches and the sum of their elapsed times (ms), each reduced by the elapsed time of an empty
+ * event pair calibrated on the same stream. Adds two event records per launch - use it on extra steps, not inside a
+ * throughput-timed region. */
 ikf_status ikf_profile_begin(ikf_model* m);
 ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream);
+/* What an empty hipEvent pair measured on that stream in the last ikf_profile_end (already subtracted per launch). */
+double ikf_profile_event_overhead_ms(const ikf_model* m);
 /* Arithmetic of the hidden Linear contractions (99 % of the FLOPs):
  *   0 = exact f32 on v_mfma_f32_32x32x2_f32 (default);
  *   1 = error-compensated f16 split on v_mfma_f32_32x32x16_f16 (a = hi + lo/2048 for both operands, three products,
