@@ -9,7 +9,7 @@ import os
 
 from ikflow_amd import build as _build
 
-IKF_ABI_VERSION = 1
+IKF_ABI_VERSION = 2
 IKF_MAX_DOF = 8
 IKF_MAX_DIM = 16
 IKF_MAX_ROUNDS = 8
@@ -43,6 +43,7 @@ class ikf_model_desc(C.Structure):
         ("joint_hi", C.c_float * IKF_MAX_DOF),
         ("chain", ikf_joint * IKF_MAX_DOF),
         ("tool", C.c_float * 12),
+        ("sigmoid_on_output", C.c_int32),
     ]
 
 

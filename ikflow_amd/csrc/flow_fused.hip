@@ -512,7 +512,11 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
     const int r = idx / f.ndof, j = idx - r * f.ndof;
     if (m0 + r >= f.M) continue;
     float q = 0.f;
-    for (int k = 0; k < D; ++k) q = fmaf(sn[r * ROWBUF + k] - f.b_lin[k], f.M_inv[k * D + j], q);
+    for (int k = 0; k < D; ++k) {
+      float xv = sn[r * ROWBUF + k];
+      if (f.sigmoid) xv = 1.0f / (1.0f + expf(-xv));  // InvertibleSigmoidFlipped rev (ikflow/model.py:124-127)
+      q = fmaf(xv - f.b_lin[k], f.M_inv[k * D + j], q);
+    }
     if (f.clamp_limits) q = fminf(fmaxf(q, f.lo[j]), f.hi[j]);
     f.q_out[(size_t)(m0 + r) * f.ndof + j] = q;
   }

@@ -610,7 +610,8 @@ __global__ __launch_bounds__(256) void k_last_layer_coupling(const float* __rest
         if (lane < D) ca.x_out[(size_t)row * D + lane] = v;
       } else {
         // FixedLinearTransform rev: (x - b).mm(M_inv); then [:, :ndof] and clamp_to_joint_limits
-        const float xm = (lane < D) ? v - ca.b_lin[lane] : 0.f;
+        const float vs = ca.sigmoid ? 1.0f / (1.0f + expf(-v)) : v;  // InvertibleSigmoidFlipped rev
+        const float xm = (lane < D) ? vs - ca.b_lin[lane] : 0.f;
         float q = 0.f;
         const int jcol = lane < D ? lane : 0;
         for (int k = 0; k < D; ++k) q = fmaf(__shfl(xm, k, 64), ca.M_inv[k * D + jcol], q);

@@ -119,6 +119,8 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   const int D = desc->dim;
   if (desc->nb_nodes < 1 || D < 2 || D > IKF_MAX_DIM) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: nb_nodes/dim out of range (2 <= D <= 16)");
   if (desc->dim_cond != 7 && desc->dim_cond != 8) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: dim_cond must be 7 or 8");
+  if (desc->sigmoid_on_output && desc->dim_cond != 7)
+    return fail(IKF_ERR_BAD_ARGUMENT, "sigmoid_on_output and softflow are incompatible, disable one or the other");
   if (desc->n_hidden < 1 || desc->n_hidden > 4) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: Number of layers `n_layers` must be in [1, ..., 4]");
   if (desc->width < 256 || desc->width % 256 != 0 || desc->width > 1024)
     return fail(IKF_ERR_BAD_SHAPE, "ikf_create: coeff_fn_internal_size must be 256, 512, 768 or 1024 for the gfx950 kernels");
@@ -263,7 +265,8 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
 
   size_t cur = 0;
   for (int b = 0; b < NB; ++b) {
-    const std::string pkey = "module_list." + std::to_string(2 * b + 1) + ".perm_inv";
+    const int moff = m->desc.sigmoid_on_output ? 1 : 0;
+    const std::string pkey = "module_list." + std::to_string(2 * b + 1 + moff) + ".perm_inv";
     const ikf_tensor* tp = nullptr;
     ikf_status st = need(idx, pkey, 1, {D}, &tp);
     if (st != IKF_OK) return st;
@@ -278,7 +281,7 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
       const int si = 2 * b + which - 1;
       const int n_x = (which == 1) ? d.L1 : d.L2;
       const int n_out = 2 * ((which == 1) ? d.L2 : d.L1);
-      const std::string base = "module_list." + std::to_string(2 * b + 2) + ".subnet" + std::to_string(which) + ".";
+      const std::string base = "module_list." + std::to_string(2 * b + 2 + moff) + ".subnet" + std::to_string(which) + ".";
       // first Linear: weight [W][n_x + C] -> transposed [n_x + 7][W] (+ softflow column apart)
       const ikf_tensor *tw = nullptr, *tb = nullptr;
       st = need(idx, base + "0.weight", 0, {W, n_x + C}, &tw);
@@ -515,7 +518,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   FinalizeArgs f{};
   f.pend = pend; f.x_src = x_src; f.M = (int)nr; f.D = d.D; f.L1 = d.L1; f.ndof = d.ndof; f.clamp = d.clamp;
   f.M_inv = m->d_Minv; f.b_lin = m->d_blin; f.lo = chain_lo(m); f.hi = chain_hi(m);
-  f.clamp_limits = clamp_limits; f.q_out = d_q_out + (size_t)r0 * d.ndof;
+  f.clamp_limits = clamp_limits; f.sigmoid = m->desc.sigmoid_on_output ? 1 : 0; f.q_out = d_q_out + (size_t)r0 * d.ndof;
   IKF_HIP(launch_flow_finalize(f, s));
   return IKF_OK;
 }
@@ -552,6 +555,7 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
       ca.which = which;
       ca.is_final = (b == 0 && which == 2) ? 1 : 0;
       ca.clamp_limits = clamp_limits;
+      ca.sigmoid = m->desc.sigmoid_on_output ? 1 : 0;
       IKF_HIP(launch_last_layer_coupling(w, d, cur, ca, nr, s));
     }
   }

@@ -55,6 +55,7 @@ struct CouplingArgs {
   int which;           // 1 or 2
   int is_final;        // last executed block, subnet 2: apply FixedLinearTransform^-1, slice, clamp
   int clamp_limits;
+  int sigmoid;         // sigmoid_on_output graph: 1/(1+exp(-x)) before the linear transform
 };
 hipError_t launch_last_layer_coupling(const SubnetWeights& w, const FlowDims& d, const float* h_in,
                                       const CouplingArgs& ca, long long rows, hipStream_t s);
@@ -112,6 +113,7 @@ struct FinalizeArgs {
   const float* lo;
   const float* hi;
   int clamp_limits;
+  int sigmoid;         // apply 1/(1+exp(-x)) before the linear transform (sigmoid_on_output graph)
   float* q_out;        // [M][ndof]
 };
 int fused_pick_cfg(long long rows, int width);  // tile configuration for a batch (-1: width not supported)

@@ -56,6 +56,7 @@ def _make_desc(layout: FlowLayout, robot: Robot) -> _lib.ikf_model_desc:
     d.width, d.n_hidden = layout.width, layout.n_hidden
     d.clamp, d.leaky_slope = layout.clamp, LEAKY_RELU_SLOPE
     d.ndof = robot.ndof
+    d.sigmoid_on_output = 1 if getattr(layout, "sigmoid_on_output", False) else 0
     if robot.ndof > _lib.IKF_MAX_DOF:
         raise EngineError(f"robot has {robot.ndof} dof; the engine supports at most {_lib.IKF_MAX_DOF}")
     for i, (lo, hi) in enumerate(robot.actuated_joints_limits):

@@ -21,6 +21,7 @@ import numpy as np
 
 from ikflow_amd.robots import Robot
 
+SIGMOID_SCALING_ABS_MAX = 1.0  # ikflow/config.py:31
 LEAKY_RELU_SLOPE = 0.01  # torch.nn.LeakyReLU() default, ikflow/model.py:63-95
 ATAN_CLAMP_GAIN = 0.636  # FrEIA GLOWCouplingBlock clamp_activation="ATAN": s = clamp * 0.636 * atan(s)
 
@@ -89,6 +90,13 @@ class FlowLayout:
     n_hidden: int  # coeff_fn_config = number of width x width-or-in x width Linear layers before the output layer
     clamp: float
     ndof: int
+    sigmoid_on_output: bool = False  # ikflow/model.py:304-307 graph variant: scaling node + flipped sigmoid in front
+
+    @property
+    def module_offset(self) -> int:
+        """Index shift of the permutation / coupling modules in GraphINN.module_list: the sigmoid variant has two
+        leading modules (IkFlowFixedLinearTransform, InvertibleSigmoidFlipped) instead of one."""
+        return 1 if self.sigmoid_on_output else 0
 
     @property
     def split1(self) -> int:  # ikflow/model.py:336  (old FrEIA rule: D // 2)
@@ -130,7 +138,6 @@ def layout_from(hparams: IkflowModelParameters, robot: Robot) -> FlowLayout:
         hparams.sigmoid_on_output = False  # ikflow_solver.py:43-44
     if hparams.softflow_enabled:
         assert not hparams.sigmoid_on_output, "sigmoid_on_output and softflow are incompatible, disable one or the other"
-    assert not hparams.sigmoid_on_output, "sigmoid_on_output graph variant is not built (SURVEY 8 f-4: no released model uses it)"
     assert hparams.coeff_fn_config in (1, 2, 3, 4), "Number of layers `n_layers` must be in [1, ..., 4]"
     dim_cond = 8 if hparams.softflow_enabled else 7
     return FlowLayout(
@@ -141,6 +148,7 @@ def layout_from(hparams: IkflowModelParameters, robot: Robot) -> FlowLayout:
         n_hidden=int(hparams.coeff_fn_config),
         clamp=float(hparams.rnvp_clamp),
         ndof=robot.ndof,
+        sigmoid_on_output=bool(hparams.sigmoid_on_output),
     )
 
 
@@ -149,16 +157,17 @@ def layout_from(hparams: IkflowModelParameters, robot: Robot) -> FlowLayout:
 # scripts/download_model_from_wandb_checkpoint.py:13-28).  Block i: permutation at module 2i+1,
 # coupling block at module 2i+2; Linear layers sit at even indices of the nn.Sequential (0,2,4,6).
 # ---------------------------------------------------------------------------------------------------
-def key_perm(i: int) -> str:
-    return f"module_list.{2 * i + 1}.perm"
+def key_perm(i: int, off: int = 0) -> str:
+    return f"module_list.{2 * i + 1 + off}.perm"
 
 
-def key_perm_inv(i: int) -> str:
-    return f"module_list.{2 * i + 1}.perm_inv"
+def key_perm_inv(i: int, off: int = 0) -> str:
+    return f"module_list.{2 * i + 1 + off}.perm_inv"
 
 
-def key_linear(i: int, subnet: int, layer: int, what: str) -> str:
-    return f"module_list.{2 * i + 2}.subnet{subnet}.{2 * layer}.{what}"
+def key_linear(i: int, subnet: int, layer: int, what: str, off: int = 0) -> str:
+    """`off` = FlowLayout.module_offset (1 for the sigmoid_on_output graph, else 0)."""
+    return f"module_list.{2 * i + 2 + off}.subnet{subnet}.{2 * layer}.{what}"
 
 
 def freia_permutation(dim: int, seed: int) -> np.ndarray:
@@ -172,6 +181,19 @@ def fixed_linear_transform(layout: FlowLayout, robot: Robot) -> Tuple[np.ndarray
     x_invSig = diag(1 / max(|lo_i|, |hi_i|)) in float32, M = x_invSig.t(), M_inv = M.inverse() (fp32 LU), b = 0."""
     import torch
 
+    if layout.sigmoid_on_output:
+        # get_pre_sigmoid_scaling_node (ikflow/model.py:241-288): joints [lo, hi] -> [0, 1]; the padding columns
+        # [-SIGMOID_SCALING_ABS_MAX, +SIGMOID_SCALING_ABS_MAX] -> [0, 1] (ikflow/config.py:31: 1.0)
+        scaling = torch.eye(layout.dim)
+        offset = torch.zeros(layout.dim)
+        for i in range(layout.dim):
+            lo, hi = robot.actuated_joints_limits[i] if i < robot.ndof else (-SIGMOID_SCALING_ABS_MAX, SIGMOID_SCALING_ABS_MAX)
+            slope = (1.0 - 0.0) / (hi - lo)
+            offset[i] = 0.0 - (slope * lo)
+            scaling[i, i] = slope
+        M = scaling.t().contiguous()
+        M_inv = scaling.t().inverse().contiguous()
+        return M.numpy().copy(), M_inv.numpy().copy(), offset.unsqueeze(0).numpy().copy()
     x_inv_sig = torch.eye(layout.dim)
     for i in range(robot.ndof):
         lo, hi = robot.actuated_joints_limits[i]
@@ -200,12 +222,13 @@ def random_state_dict(
     sd["module_list.0.M"] = M
     sd["module_list.0.M_inv"] = M_inv
     sd["module_list.0.b"] = b
+    off = layout.module_offset
     for i in range(layout.nb_nodes):
         perm = freia_permutation(layout.dim, i)
         perm_inv = np.zeros_like(perm)
         perm_inv[perm] = np.arange(layout.dim)
-        sd[key_perm(i)] = perm
-        sd[key_perm_inv(i)] = perm_inv
+        sd[key_perm(i, off)] = perm
+        sd[key_perm_inv(i, off)] = perm_inv
         for subnet in (1, 2):
             dims = layout.subnet_dims(subnet)
             for layer, (cin, cout) in enumerate(dims):
@@ -215,8 +238,8 @@ def random_state_dict(
                 if layer == len(dims) - 1:
                     w = w * output_gain
                     bb = bb * output_gain
-                sd[key_linear(i, subnet, layer, "weight")] = w.numpy().copy()
-                sd[key_linear(i, subnet, layer, "bias")] = bb.numpy().copy()
+                sd[key_linear(i, subnet, layer, "weight", off)] = w.numpy().copy()
+                sd[key_linear(i, subnet, layer, "bias", off)] = bb.numpy().copy()
     return sd
 
 
@@ -228,15 +251,16 @@ def validate_state_dict(layout: FlowLayout, sd: Dict[str, np.ndarray]) -> None:
             missing.append(k)
         elif tuple(sd[k].shape) != (layout.dim, layout.dim):
             bad.append((k, tuple(sd[k].shape), (layout.dim, layout.dim)))
+    off = layout.module_offset
     for i in range(layout.nb_nodes):
-        k = key_perm_inv(i)
+        k = key_perm_inv(i, off)
         if k not in sd:
             missing.append(k)
         elif tuple(sd[k].shape) != (layout.dim,):
             bad.append((k, tuple(sd[k].shape), (layout.dim,)))
         for subnet in (1, 2):
             for layer, (cin, cout) in enumerate(layout.subnet_dims(subnet)):
-                kw, kb = key_linear(i, subnet, layer, "weight"), key_linear(i, subnet, layer, "bias")
+                kw, kb = key_linear(i, subnet, layer, "weight", off), key_linear(i, subnet, layer, "bias", off)
                 if kw not in sd:
                     missing.append(kw)
                 elif tuple(sd[kw].shape) != (cout, cin):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IKF_ABI_VERSION 1
+#define IKF_ABI_VERSION 2
 #define IKF_MAX_DOF 8     /* actuated joints on the chain                      */
 #define IKF_MAX_DIM 16    /* flow width D (dim_latent_space)                   */
 #define IKF_MAX_ROUNDS 8  /* len(repeat_counts)                                */
@@ -70,6 +70,9 @@ typedef struct ikf_model_desc {
   float joint_hi[IKF_MAX_DOF];
   ikf_joint chain[IKF_MAX_DOF];
   float tool[12];             /* 3x4 fixed transform after the last joint (end-effector frame)      */
+  int32_t sigmoid_on_output;  /* model.py:304-307 graph variant: module_list.0 = scaling node, .1 = flipped
+                                 sigmoid (applied before the linear transform in the inverse pass); permutation /
+                                 coupling modules shift to 2i+2 / 2i+3                               */
 } ikf_model_desc;
 
 /* One named tensor of the reference's state_dict (FrEIA GraphINN key names, ikflow_solver.py:413-429). */

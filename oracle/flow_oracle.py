@@ -15,6 +15,8 @@ not installed; what is restated below is FrEIA's published algorithm for the thr
                                    s2 = clamp*(0.636*atan(s2));  y1 = (x1 - t2)*exp(-s2);  out = cat[y1,y2]
   PermuteRandom (rev)            : x[:, perm_inv]
   FixedLinearTransform (rev)     : (x - b).mm(M_inv)      (in-tree twin of the same algebra: ikflow/model.py:220)
+  sigmoid_on_output variant      : InvertibleSigmoidFlipped rev = 1/(1+exp(-x)) (ikflow/model.py:124-127), then the
+                                   scaling node's (x - b).mm(M_inv) with M, b of get_pre_sigmoid_scaling_node (:241-288)
   subnet                         : Linear/LeakyReLU(0.01) stack, ikflow/model.py:51-96
 
 ``flow_inverse_torch`` uses the same torch CPU ops the reference would run (F.linear -> MKL sgemm, leaky_relu,
@@ -43,10 +45,11 @@ def _t(a) -> torch.Tensor:
 def subnet_torch(sd: Dict, layout: FlowLayout, block: int, which: int, u: torch.Tensor) -> torch.Tensor:
     """ikflow/model.py:51-96 - Linear, LeakyReLU, ..., Linear."""
     n_lin = layout.n_hidden + 1
+    off = layout.module_offset
     h = u
     for layer in range(n_lin):
-        w = _t(sd[key_linear(block, which, layer, "weight")])
-        b = _t(sd[key_linear(block, which, layer, "bias")])
+        w = _t(sd[key_linear(block, which, layer, "weight", off)])
+        b = _t(sd[key_linear(block, which, layer, "bias", off)])
         h = F.linear(h, w, b)
         if layer != n_lin - 1:
             h = F.leaky_relu(h, LEAKY_RELU_SLOPE)
@@ -74,7 +77,9 @@ def flow_inverse_torch(
             s2 = clamp * (ATAN_CLAMP_GAIN * torch.atan(s2))
             y1 = (x1 - t2) * torch.exp(-s2)
             x = torch.cat((y1, y2), 1)
-            x = x[:, _t(sd[key_perm_inv(i)]).long()]
+            x = x[:, _t(sd[key_perm_inv(i, layout.module_offset)]).long()]
+        if layout.sigmoid_on_output:
+            x = 1 / (1 + torch.exp(-x))  # InvertibleSigmoidFlipped, rev branch (ikflow/model.py:124-127)
         b = _t(sd["module_list.0.b"]) if "module_list.0.b" in sd else 0.0
         x = (x - b).mm(_t(sd["module_list.0.M_inv"]))
     return x
@@ -119,8 +124,8 @@ def flow_inverse_f64(sd: Dict, layout: FlowLayout, latent: np.ndarray, condition
     def subnet(block, which, u):
         h = u
         for layer in range(n_lin):
-            w = np.asarray(sd[key_linear(block, which, layer, "weight")], dtype=np.float64)
-            b = np.asarray(sd[key_linear(block, which, layer, "bias")], dtype=np.float64)
+            w = np.asarray(sd[key_linear(block, which, layer, "weight", layout.module_offset)], dtype=np.float64)
+            b = np.asarray(sd[key_linear(block, which, layer, "bias", layout.module_offset)], dtype=np.float64)
             h = h @ w.T + b
             if layer != n_lin - 1:
                 h = np.where(h > 0, h, slope * h)
@@ -136,7 +141,9 @@ def flow_inverse_f64(sd: Dict, layout: FlowLayout, latent: np.ndarray, condition
         a2 = subnet(i, 2, np.concatenate([y2, c], 1))
         s2, t2 = a2[:, :L1], a2[:, L1:]
         y1 = (x1 - t2) * np.exp(-(clamp * (gain * np.arctan(s2))))
-        x = np.concatenate([y1, y2], 1)[:, np.asarray(sd[key_perm_inv(i)], dtype=np.int64)]
+        x = np.concatenate([y1, y2], 1)[:, np.asarray(sd[key_perm_inv(i, layout.module_offset)], dtype=np.int64)]
+    if layout.sigmoid_on_output:
+        x = 1.0 / (1.0 + np.exp(-x))
     b = np.asarray(sd["module_list.0.b"], dtype=np.float64) if "module_list.0.b" in sd else 0.0
     return (x - b) @ np.asarray(sd["module_list.0.M_inv"], dtype=np.float64)
 

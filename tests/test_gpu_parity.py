@@ -102,6 +102,27 @@ def test_flow_f16_split_precision_matches_oracle(which, n):
     assert (clamped - ref_cl).abs().max().item() <= FLOW_TOL
 
 
+def test_sigmoid_on_output_variant_matches_oracle_and_stays_in_limits():
+    """ikflow/model.py:304-307 graph (scaling node + flipped sigmoid, no softflow -> 7-entry conditional);
+    reference tests/model_test.py:108-123 property on the HIP path."""
+    from test_oracle_golden import _sigmoid_model
+
+    robot, hp, lay, sd = _sigmoid_model(seed=1)
+    s = _solver(robot, hp, sd)
+    assert s.conditional_size == 7
+    n = 300
+    _, poses = reachable_poses(robot, n, 3)
+    lat = latents(n, lay.dim, 4)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+    got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
+    assert (got - ref).abs().max().item() <= FLOW_TOL
+    wild = 1e8 * latents(n, lay.dim, 5)
+    out = s.generate_ik_solutions(poses.to(DEV), latent=wild.to(DEV), clamp_to_joint_limits=False).cpu()
+    assert bool(torch.isfinite(out).all())
+    for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+        assert out[:, i].min().item() >= lo - 1e-5 and out[:, i].max().item() <= hi + 1e-5
+
+
 def test_flow_fetch_arm_matches_oracle():
     got, ref32, ref64 = _flow_case(fetch_arm_model(), 200)
     assert (got - ref32).abs().max().item() <= FLOW_TOL

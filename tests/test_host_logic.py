@@ -32,7 +32,7 @@ def test_cabi_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} is declared in include/ikflow_amd.h but not exported"
     assert lib.ikf_abi_version() == _lib.IKF_ABI_VERSION
     assert lib.ikf_dominant_kernel_name().decode() == "k_flow_gemm"
-    assert ctypes.sizeof(_lib.ikf_joint) == 4 + 12 + 48 and ctypes.sizeof(_lib.ikf_model_desc) == 9 * 4 + 2 * 32 + 8 * 64 + 48
+    assert ctypes.sizeof(_lib.ikf_joint) == 4 + 12 + 48 and ctypes.sizeof(_lib.ikf_model_desc) == 9 * 4 + 2 * 32 + 8 * 64 + 48 + 4
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -196,3 +196,48 @@ def test_exact_ik_oracle_control_flow_invariants():
     assert (pe < 0.2).all() and (re < 1.0).all()
     sol1, valid1 = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats[:1], (1,), 0.2, 1.0)
     assert torch.equal(sol[valid1], sol1[valid1]) and bool((valid | ~valid1).all())
+
+
+# ---- sigmoid_on_output graph variant (ikflow/model.py:304-307; reference tests/model_test.py:50-123) ----------------
+def _sigmoid_model(seed=0):
+    from ikflow_amd.model import IkflowModelParameters, random_state_dict
+
+    hp = IkflowModelParameters()
+    hp.nb_nodes, hp.coeff_fn_config, hp.coeff_fn_internal_size = 3, 2, 256
+    hp.dim_latent_space = 9
+    hp.softflow_enabled = False
+    hp.sigmoid_on_output = True
+    robot = Panda()
+    lay = layout_from(hp, robot)
+    return robot, hp, lay, random_state_dict(lay, robot, seed=seed)
+
+
+def test_pre_sigmoid_scaling_node_maps_limits_to_unit_interval():
+    """tests/model_test.py:50-106: upper limits -> 1, lower limits -> 0, midpoints -> 0.5 (forward y = x M + b),
+    and the reverse (x - b) M_inv maps them back."""
+    robot, hp, lay, sd = _sigmoid_model()
+    M, M_inv, b = fixed_linear_transform(lay, robot)
+    upper = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 1.0, 1.0], dtype=np.float32)
+    lower = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, -1.0, -1.0], dtype=np.float32)
+    mid = np.array([0.0, 0.0, 0.0, -1.5708, 0.0, 1.8675, 0.0, 0.0, 0.0], dtype=np.float32)
+    np.testing.assert_allclose(upper @ M + b[0], np.ones(9), atol=1e-5)
+    np.testing.assert_allclose(lower @ M + b[0], np.zeros(9), atol=1e-5)
+    np.testing.assert_allclose(mid @ M + b[0], 0.5 * np.ones(9), atol=1e-5)
+    np.testing.assert_allclose((np.ones(9, np.float32) - b[0]) @ M_inv, upper, atol=1e-5)
+    np.testing.assert_allclose((np.zeros(9, np.float32) - b[0]) @ M_inv, lower, atol=1e-5)
+    assert lay.module_offset == 1 and lay.dim_cond == 7
+    assert "module_list.3.subnet1.0.weight" in sd and "module_list.2.perm_inv" in sd and "module_list.1.perm" not in sd
+
+
+def test_sigmoid_on_output_always_inside_joint_limits():
+    """tests/model_test.py:108-123: even 1e8 * N(0,1) latents come out inside the joint limits (unclamped)."""
+    robot, hp, lay, sd = _sigmoid_model(seed=1)
+    n = 50
+    g = torch.Generator().manual_seed(0)
+    for scale in (1.0, 1e8):
+        lat = scale * torch.randn(n, lay.dim, generator=g)
+        poses = torch.randn(n, 7, generator=g)
+        out = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+        assert bool(torch.isfinite(out).all())
+        for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+            assert out[:, i].min().item() >= lo - 1e-5 and out[:, i].max().item() <= hi + 1e-5
