@@ -275,16 +275,12 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
         *reinterpret_cast<floatx4*>(sp_ + BM * LDK + i * RS * LDK) = rb[S][i];                                    \
   }
-#if defined(IKF_ABLATE) && IKF_ABLATE == 3
-#define IKF_FRAG(FA, FB, stage, kk) {}
-#else
 #define IKF_FRAG(FA, FB, stage, kk)                                                                               \
   {                                                                                                               \
     const float* sp_ = smem + (stage) * STAGE + (kk) * 8;                                                         \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) FA[i] = *reinterpret_cast<const floatx4*>(sp_ + fragA + i * 32 * LDK); \
     _Pragma("unroll") for (int j = 0; j < NI; ++j) FB[j] = *reinterpret_cast<const floatx4*>(sp_ + fragB + j * 32 * LDK); \
   }
-#endif
 #define IKF_MFMA4(FA, FB)                                                                                         \
   {                                                                                                               \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) {                \
@@ -340,9 +336,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
         }
       }
     }
-#if !defined(IKF_ABLATE) || IKF_ABLATE != 1
     __syncthreads();
-#endif
 #pragma unroll
     for (int kk = NKK / 2; kk < NKK; ++kk) {
       if (kk + 1 < NKK) {

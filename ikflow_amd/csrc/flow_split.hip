@@ -30,16 +30,22 @@ extern __device__ unsigned long long* ikf_trace_buf;  // defined in flow_fused.h
 #define IKS_TSTAMP(i)
 #endif
 
-constexpr int SBM = 128, SBN = 128, SWAVES_M = 2;
-#ifndef IKF_SPLIT_WAVES_N
-#define IKF_SPLIT_WAVES_N 2
-#endif
-constexpr int SWAVES_N = IKF_SPLIT_WAVES_N;  // 2: 4 waves of 64x64 (1 per SIMD); 4: 8 waves of 64x32 (2 per SIMD)
-constexpr int SNT = SWAVES_M * SWAVES_N * 64;
+// tile configurations (chosen by row count so that small batches still spread over the chip):
+//   0: 128x128, 4 waves of 64x64   1: 64x128, 4 waves of 32x64   2: 64x64, 4 waves of 32x32   3: 32x64, 2 waves of 32x32
+template <int CFG> struct SplitCfg;
+template <> struct SplitCfg<0> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 2; };
+template <> struct SplitCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M = 2, WAVES_N = 2; };
+template <> struct SplitCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2; };
+template <> struct SplitCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2; };
+constexpr int kNumSplitCfg = 4;
+static const int kSplitBM[kNumSplitCfg] = {128, 64, 64, 32};
+static const int kSplitBN[kNumSplitCfg] = {128, 128, 64, 64};
 
-template <bool EPI_RED>
-__global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
-  constexpr int BM = SBM, BN = SBN, NT = SNT;
+template <bool EPI_RED, int CFG>
+__global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64) void k_split_gemm(SplitGemmArgs g) {
+  using TC = SplitCfg<CFG>;
+  constexpr int BM = TC::BM, BN = TC::BN, SWAVES_M = TC::WAVES_M, SWAVES_N = TC::WAVES_N;
+  constexpr int NT = SWAVES_M * SWAVES_N * 64;
   constexpr int WM = BM / SWAVES_M, WN = BN / SWAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int LDK = 36;            // dwords per stage row: 128 B line + 16 B pad
@@ -306,10 +312,22 @@ __global__ __launch_bounds__(SNT) void k_split_gemm(SplitGemmArgs g) {
 
 const char* split_kernel_name() { return "k_split_gemm"; }
 
-template <bool EPI_RED>
+int split_pick_cfg(long long rows, int width) {
+  for (int c = 0; c < kNumSplitCfg; ++c) {
+    if (width % kSplitBN[c] != 0) continue;
+    const long long tiles = ((rows + kSplitBM[c] - 1) / kSplitBM[c]) * (width / kSplitBN[c]);
+    if (tiles >= 256) return c;
+  }
+  for (int c = kNumSplitCfg - 1; c >= 0; --c)
+    if (width % kSplitBN[c] == 0) return c;
+  return -1;
+}
+
+template <bool EPI_RED, int CFG>
 static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = (size_t)3 * (SBM + SBN) * 36 * sizeof(float);
-  auto kern = k_split_gemm<EPI_RED>;
+  using TC = SplitCfg<CFG>;
+  constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * 36 * sizeof(float);
+  auto kern = k_split_gemm<EPI_RED, CFG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -317,16 +335,21 @@ static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  const long long tiles_m = ((long long)a.M + SBM - 1) / SBM;
-  const long long grid = tiles_m * (a.N / SBN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(SNT), smem, s, a);
+  const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
+  const long long grid = tiles_m * (a.N / TC::BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TC::WAVES_M * TC::WAVES_N * 64), smem, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_split_gemm(bool epi_red, const SplitGemmArgs& a, hipStream_t s) {
+hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (a.N % SBN != 0 || a.K % 32 != 0 || a.n_out > 16) return hipErrorInvalidValue;
-  return epi_red ? launch_sg<true>(a, s) : launch_sg<false>(a, s);
+  if (cfg < 0 || cfg >= kNumSplitCfg || a.N % kSplitBN[cfg] != 0 || a.K % 32 != 0 || a.n_out > 16) return hipErrorInvalidValue;
+  switch (cfg) {
+    case 0: return epi_red ? launch_sg<true, 0>(a, s) : launch_sg<false, 0>(a, s);
+    case 1: return epi_red ? launch_sg<true, 1>(a, s) : launch_sg<false, 1>(a, s);
+    case 2: return epi_red ? launch_sg<true, 2>(a, s) : launch_sg<false, 2>(a, s);
+    default: return epi_red ? launch_sg<true, 3>(a, s) : launch_sg<false, 3>(a, s);
+  }
 }
 
 // device: fp32 [rows][K] -> split-32 image; one thread converts 8 consecutive k of a row

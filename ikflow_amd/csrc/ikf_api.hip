@@ -498,7 +498,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
         sg.A = cur; sg.C = last ? nullptr : nxt; sg.W = m->w_mid_split[(size_t)(2 * b + which - 1) * 3 + l];
         sg.bias = w.b_mid[l]; sg.M = (int)nr; sg.N = d.width; sg.K = d.width; sg.slope = d.slope;
         sg.w_last = w.w_last; sg.n_out = w.n_out; sg.P_out = m->pbuf; sg.p_slot_stride = rows_pad * IKF_PSTRIDE;
-        IKF_HIP(launch_split_gemm(last, sg, s));
+        IKF_HIP(launch_split_gemm(last, (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width), sg, s));
       } else {
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
         IKF_HIP(launch_flow_gemm(last, cfg, g, s));

@@ -143,7 +143,8 @@ struct SplitGemmArgs {
   float* P_out;
   long long p_slot_stride;
 };
-hipError_t launch_split_gemm(bool epi_red, const SplitGemmArgs& a, hipStream_t s);
+hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s);
+int split_pick_cfg(long long rows, int width);
 void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // host-side packer (probe tool)
 hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, hipStream_t s);
 const char* split_kernel_name();
