@@ -517,7 +517,207 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Small batches (rows <= 512): the 32x32 f32 MFMA block of one wave over K = 1024 is 512 dependent-issue MFMAs =
+// 32768 cycles whatever the tile, so the launch is latency-bound (16 us) and half the SIMDs idle.  This form splits K
+// INSIDE the workgroup: tile 32x64, BK = 128 per stage, 8 waves = 2 column halves x 4 k-quarters; every wave issues 16
+// MFMAs per stage (128 per launch), two stages, one barrier per stage; the four k-quarter partial blocks are summed
+// through LDS in fixed order kq = 0,1,2,3.  (The quarter split changes the summation order with respect to the large
+// tiles: results agree to rounding, not bit for bit, across the 1024-row boundary.)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KBM = 32, KBN = 64, KBK = 128, KNT = 512;
+
+template <bool EPI_RED>
+__global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
+  constexpr int BM = KBM, BN = KBN, BK = KBK, NT = KNT;
+  constexpr int LDK = BK + 4;
+  constexpr int KQ4 = BK / 4;                 // float4 per tile row
+  constexpr int NF4 = (BM + BN) * KQ4 / NT;   // float4 per thread per stage (A rows first, then W rows)
+  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int LDT = BN + 4;
+  static_assert((BM + BN) * KQ4 % NT == 0, "tile/threads mismatch");
+  static_assert(3 * STAGE >= 3 * 2 * 16 * 64 && 3 * STAGE >= (BM + 32) * LDT, "reduction/epilogue scratch must fit");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][LDK]
+
+  const int M = g.M, N = g.N, K = g.K;
+  const int tiles_n = N / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int nh = wave & 1, kq = wave >> 1;
+
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // staging: float4 f = t + i*NT of the stage image; rows 0..BM-1 are A rows, BM.. are W rows
+  const float* src[NF4];
+  int ldst[NF4];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) {
+    const int f = t + i * NT, row = f / KQ4, c4 = f - row * KQ4;
+    if (row < BM) {
+      int gr = m0 + row;
+      gr = gr < M ? gr : M - 1;
+      src[i] = g.A + (size_t)gr * K + c4 * 4;
+    } else {
+      src[i] = g.W + (size_t)(n0 + row - BM) * K + c4 * 4;
+    }
+    ldst[i] = row * LDK + c4 * 4;
+  }
+  const int fragA = (lane & 31) * LDK + kq * 32 + (lane >> 5) * 4;
+  const int fragB = (BM + nh * 32 + (lane & 31)) * LDK + kq * 32 + (lane >> 5) * 4;
+  const int KT = K / BK;
+
+  floatx4 rg[NF4];
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) rg[i] = *reinterpret_cast<const floatx4*>(src[i]);
+#pragma unroll
+  for (int i = 0; i < NF4; ++i) *reinterpret_cast<floatx4*>(smem + ldst[i]) = rg[i];
+  if (KT > 1) {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) rg[i] = *reinterpret_cast<const floatx4*>(src[i] + BK);
+  }
+  __syncthreads();
+
+#define IKK_FRAG(FA, FB, stage, kk)                                                       \
+  {                                                                                       \
+    FA = *reinterpret_cast<const floatx4*>(smem + (stage) * STAGE + fragA + (kk) * 8);    \
+    FB = *reinterpret_cast<const floatx4*>(smem + (stage) * STAGE + fragB + (kk) * 8);    \
+  }
+#define IKK_MFMA(FA, FB)                                                                  \
+  {                                                                                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.x, FB.x, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.y, FB.y, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.z, FB.z, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.w, FB.w, acc, 0, 0, 0);                 \
+  }
+  // 3 stages, one barrier per stage placed mid-stage (same hazard argument as k_flow_gemm): tile kt+1 is written into
+  // stage (kt+1)%3 during the first half of stage kt, the next fragments are always read one k-group ahead
+  floatx4 fa0, fb0, fa1, fb1;
+  IKK_FRAG(fa0, fb0, 0, 0)
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const int nxt = (cur == 2) ? 0 : cur + 1;
+    const bool has1 = (kt + 1 < KT), has2 = (kt + 2 < KT);
+    IKK_FRAG(fa1, fb1, cur, 1)
+    IKK_MFMA(fa0, fb0)
+    if (has1) {
+      float* nx = smem + nxt * STAGE;
+#pragma unroll
+      for (int i = 0; i < NF4; ++i) *reinterpret_cast<floatx4*>(nx + ldst[i]) = rg[i];
+    }
+    if (has2) {
+#pragma unroll
+      for (int i = 0; i < NF4; ++i) rg[i] = *reinterpret_cast<const floatx4*>(src[i] + (kt + 2) * BK);
+    }
+    IKK_FRAG(fa0, fb0, cur, 2)
+    IKK_MFMA(fa1, fb1)
+    __syncthreads();
+    IKK_FRAG(fa1, fb1, cur, 3)
+    IKK_MFMA(fa0, fb0)
+    if (has1) IKK_FRAG(fa0, fb0, nxt, 0)
+    IKK_MFMA(fa1, fb1)
+    cur = nxt;
+  }
+#undef IKK_FRAG
+#undef IKK_MFMA
+  __syncthreads();  // all fragment reads done before the stage area is reused
+
+  // ---- sum the four k-quarter partial blocks (fixed order) in the waves of quarter 0
+  float* red = smem;  // [3][2][16][64]
+  if (kq > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(((kq - 1) * 2 + nh) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (kq == 0) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[((q * 2 + nh) * 16 + r) * 64 + lane];
+  }
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  if constexpr (!EPI_RED) {
+    if (kq == 0) {
+      const int col = n0 + nh * 32 + col_l;
+      const float bv = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
+        float v = acc[r] + bv;
+        v = v > 0.f ? v : v * g.slope;
+        g.C[(size_t)row * N + col] = v;  // row-padded buffer: unpredicated
+      }
+    }
+  } else {
+    __syncthreads();  // red[] fully consumed before T/Wl overwrite it
+    float* T = smem;
+    float* Wl = smem + BM * LDT;
+    if (kq == 0) {
+      const int cl = nh * 32 + col_l;
+      const float bv = g.bias[n0 + cl];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + row_h;
+        float v = acc[r] + bv;
+        v = v > 0.f ? v : v * g.slope;
+        T[rl * LDT + cl] = v;
+      }
+    }
+    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
+      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (wave == 0) {  // one 64-column slot per tile, same MFMA order as every other configuration
+      floatx16 pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      const float* pa = Wl + (lane & 31) * LDT + (lane >> 5) * 4;
+      const float* pb = T + (lane & 31) * LDT + (lane >> 5) * 4;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+      }
+      float* pout = g.P_out + (size_t)(n0 / 64) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + row_h;
+        pout[o] = pacc[r];
+      }
+    }
+  }
+}
+
+template <bool EPI_RED>
+static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = (size_t)3 * (KBM + KBN) * (KBK + 4) * sizeof(float);
+  auto kern = k_flow_gemm_skinny<EPI_RED>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / KBN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KNT), smem, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSkinnyCfg = 4;  // k_flow_gemm_skinny
 int fused_pick_cfg(long long rows, int width) {
+  if (rows <= 512 && width % KBN == 0 && width % KBK == 0) return kSkinnyCfg;
   for (int c = 0; c < kNumTileCfg; ++c) {
     if (width % kCfgBN[c] != 0) continue;
     const long long tiles = ((rows + kCfgBM[c] - 1) / kCfgBM[c]) * (width / kCfgBN[c]);
@@ -557,6 +757,10 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
 
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
+  if (cfg == kSkinnyCfg) {
+    if (a.N % KBN != 0 || a.K % KBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
+    return epi_red ? launch_skinny<true>(a, s) : launch_skinny<false>(a, s);
+  }
   if (cfg < 0 || cfg >= kNumTileCfg || a.N % kCfgBN[cfg] != 0 || a.K % FBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
   switch (cfg) {
     case 0: return epi_red ? launch_fg<true, 0>(a, s) : launch_fg<false, 0>(a, s);

@@ -418,7 +418,7 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
 
 extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
-  if (variant >= 100 && variant <= 104) {  // fused pipeline; 100 = tile by batch size, 101..104 = tile config 0..3
+  if (variant >= 100 && variant <= 105) {  // fused pipeline; 100 = tile by batch size, 101..105 = tile config 0..4
     m->gemm_variant = 100;
     m->tile_cfg = variant - 101;
     return IKF_OK;
