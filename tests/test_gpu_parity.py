@@ -390,3 +390,78 @@ def test_return_detailed_tuple():
     pe_ref, re_ref = ko.calculate_pose_error(robot, ref, poses)
     assert (pe.cpu() - pe_ref).abs().max().item() < 1e-4 and (re.cpu() - re_ref).abs().max().item() < 1e-3
     assert lim.dtype == torch.bool and not bool(lim.any()) and coll is None and isinstance(rt, float)
+
+
+def test_exact_ik_retry_rounds_cross_the_flow_chunk_boundary():
+    """Tight thresholds leave (almost) every pose unsolved, so round 3 runs 10 x ~1800 = ~18000 flow rows: more than one
+    16384-row chunk, with the conditional gathered through pose_idx[row % n_active] across the chunk boundary."""
+    robot, hp, lay, sd = tiny_model(seed=2)
+    s = _solver(robot, hp, sd)
+    n, rc = 1800, (1, 3, 10)
+    poses, lats = _exact_inputs(robot, lay, n, rc, 33)
+
+    def flow_fn(latent, poses_tiled):
+        return fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses_tiled, latent[: poses_tiled.shape[0]], clamp=True)
+
+    ref_sol, ref_valid = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, 0.02, 0.1, lm_dtype=torch.float64)
+    eng = s.engine(DEV)
+    sol, valid, stats = eng.generate_exact(poses.to(DEV), rc, 0.02, 0.1, latents=[l.to(DEV) for l in lats], return_stats=True)
+    sol, valid = sol.cpu(), valid.cpu()
+    assert stats[2, 1] > 16384, stats  # third round really spans two chunks
+    assert stats[0, 0] == n and stats[1, 0] == n - stats[0, 3] and stats[2, 0] == stats[1, 0] - stats[1, 3]
+    assert int(valid.sum()) == int(stats[:, 3].sum())
+    agree = (valid == ref_valid).float().mean().item()
+    print(f"exact n={n}: valid {int(valid.sum())} (oracle {int(ref_valid.sum())}), agreement {agree:.4f}, stats {stats.tolist()}")
+    assert agree >= 0.97
+    both = (valid == ref_valid) & valid
+    d = (sol[both] - ref_sol[both]).abs().max(1).values
+    assert int((d > 1e-3).sum()) <= max(1, int(0.05 * d.numel()))
+    assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
+
+
+def test_cabi_status_codes_and_edge_sizes():
+    """C-ABI error behaviour (include/ikflow_amd.h): distinct status codes + ikf_last_error text; n = 0 is a no-op."""
+    import ctypes as C
+
+    from ikflow_amd import _lib
+    from ikflow_amd.engine import Engine, EngineError
+
+    robot, hp, lay, sd = tiny_model()
+    eng = Engine(lay, robot, DEV)
+    lib = eng.lib
+    q = torch.zeros(4, 7, device=DEV)
+    out = torch.zeros(4, 7, device=DEV)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # weights not loaded -> IKF_ERR_NOT_LOADED (the reference's assert message)
+    lat = torch.zeros(4, lay.dim, device=DEV)
+    code = lib.ikf_generate_approx(eng._h, q.data_ptr(), 0, lat.data_ptr(), 4, 1, 0.0, out.data_ptr(), stream)
+    assert code == _lib.IKF_ERR_NOT_LOADED and "Model weights have not been loaded" in _lib.last_error()
+    # kinematics work without weights; null pointer -> IKF_ERR_NULL_POINTER; n = 0 -> OK
+    assert lib.ikf_forward_kinematics(eng._h, q.data_ptr(), 4, out.data_ptr(), stream) == _lib.IKF_OK
+    assert lib.ikf_forward_kinematics(eng._h, None, 4, out.data_ptr(), stream) == _lib.IKF_ERR_NULL_POINTER
+    assert lib.ikf_forward_kinematics(eng._h, None, 0, None, stream) == _lib.IKF_OK
+    assert lib.ikf_forward_kinematics(eng._h, q.data_ptr(), -1, out.data_ptr(), stream) == _lib.IKF_ERR_BAD_ARGUMENT
+    # bad state_dict -> IKF_ERR_MISSING_TENSOR surfaced as RuntimeError by the shim
+    bad = dict(sd)
+    bad.pop("module_list.0.M_inv")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        eng.load_state_dict(bad)
+    eng.load_state_dict(sd)
+    assert eng.weights_loaded
+    assert lib.ikf_generate_approx(eng._h, q.data_ptr(), 0, lat.data_ptr(), 0, 1, 0.0, out.data_ptr(), stream) == _lib.IKF_OK
+    rc = (C.c_int32 * 1)(0)
+    cb = _lib.LATENT_FN(lambda *a: 0)
+    valid = torch.zeros(4, dtype=torch.uint8, device=DEV)
+    code = lib.ikf_generate_exact(eng._h, q.data_ptr(), 4, rc, 1, 3, 1e-3, 0.1, cb, None, out.data_ptr(), valid.data_ptr(), None, stream)
+    assert code == _lib.IKF_ERR_BAD_ARGUMENT  # repeat count 0
+    with pytest.raises(EngineError):
+        eng.set_gemm_variant(77)
+    # empty exact call through the shim
+    s = _solver(robot, hp, sd)
+    sol, v = s.generate_exact_ik_solutions(torch.zeros(0, 7, device=DEV))
+    assert sol.shape == (0, 7) and v.shape == (0,)
+    # a descriptor the kernels are not built for is refused at create time
+    from ikflow_amd.model import FlowLayout
+
+    with pytest.raises(EngineError, match="coeff_fn_internal_size"):
+        Engine(FlowLayout(nb_nodes=2, dim=9, dim_cond=8, width=300, n_hidden=2, clamp=2.5, ndof=7), robot, DEV)
