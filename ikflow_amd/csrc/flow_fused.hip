@@ -382,32 +382,21 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 
   using S0_ = std::integral_constant<int, 0>;
   using S1_ = std::integral_constant<int, 1>;
-  // iteration kt stores tile kt+1 from set (kt+1)&1 and refills that set with tile kt+3
-  int cur = 0, kt = 0;
-  for (; kt + 4 < KT; kt += 2) {
+  // iteration kt stores tile kt+1 from set (kt+1)&1 and refills that set with tile kt+3.  Every iteration runs the SAME
+  // two code bodies: near the end the prefetch index is clamped to the last tile (a redundant, harmless load + LDS
+  // write into a stage nobody reads again) - specialised tail instantiations are cold code and cost ~1000 cycles each
+  // in instruction-cache misses.
+  int cur = 0;
+  for (int kt = 0; kt < KT; kt += 2) {  // KT is even (K % 64 == 0, checked by the launcher)
     int nxt = (cur == 2) ? 0 : cur + 1;
-    k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
+    k_tile(T_{}, T_{}, S1_{}, (kt + 3 < KT ? kt : KT - 4), cur, nxt);
     cur = nxt;
     nxt = (cur == 2) ? 0 : cur + 1;
-    k_tile(T_{}, T_{}, S0_{}, kt + 1, cur, nxt);
+    k_tile(T_{}, T_{}, S0_{}, (kt + 4 < KT ? kt + 1 : KT - 4), cur, nxt);
     cur = nxt;
 #ifdef IKF_TRACE
     if ((kt & 3) == 2 && kt < 128) IKF_TSTAMP(2 + (kt >> 2))
 #endif
-  }
-  for (; kt < KT; ++kt) {  // last (up to 4) tiles: no tile kt+3 to fetch, possibly no tile kt+1 to stage
-    const int nxt = (cur == 2) ? 0 : cur + 1;
-    const bool has1 = (kt + 1 < KT), has3 = (kt + 3 < KT);
-    if (kt & 1) {
-      if (has3) k_tile(T_{}, T_{}, S0_{}, kt, cur, nxt);
-      else if (has1) k_tile(T_{}, F_{}, S0_{}, kt, cur, nxt);
-      else k_tile(F_{}, F_{}, S0_{}, kt, cur, nxt);
-    } else {
-      if (has3) k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
-      else if (has1) k_tile(T_{}, F_{}, S1_{}, kt, cur, nxt);
-      else k_tile(F_{}, F_{}, S1_{}, kt, cur, nxt);
-    }
-    cur = nxt;
   }
   IKF_TSTAMP(40)
 #undef IKF_GLOAD
@@ -761,7 +750,7 @@ hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipSt
     if (a.N % KBN != 0 || a.K % KBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
     return epi_red ? launch_skinny<true>(a, s) : launch_skinny<false>(a, s);
   }
-  if (cfg < 0 || cfg >= kNumTileCfg || a.N % kCfgBN[cfg] != 0 || a.K % FBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
+  if (cfg < 0 || cfg >= kNumTileCfg || a.N % kCfgBN[cfg] != 0 || a.K % 64 != 0 || a.K < 128 || a.n_out > 16) return hipErrorInvalidValue;
   switch (cfg) {
     case 0: return epi_red ? launch_fg<true, 0>(a, s) : launch_fg<false, 0>(a, s);
     case 1: return epi_red ? launch_fg<true, 1>(a, s) : launch_fg<false, 1>(a, s);

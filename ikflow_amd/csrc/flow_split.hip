@@ -145,8 +145,12 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
     constexpr int S = decltype(set_c)::value;
     IKS_FRAG(ah1, al1, bh1, bl1, cur, 1)
     IKS_MFMA3(ah0, al0, bh0, bl0)
+#if !defined(IKS_ABLATE) || (IKS_ABLATE != 2 && IKS_ABLATE != 4)
     if (HAS1) IKS_LSTORE(S, nxt)
+#endif
+#if !defined(IKS_ABLATE) || (IKS_ABLATE != 2 && IKS_ABLATE != 5)
     if (HAS3) IKS_GLOAD(S, kt + 3)
+#endif
     {
       constexpr int n_mfma = MI * NI * 3;
       constexpr int n_rd = 2 * (MI + NI), n_wr = HAS1 ? A_F4 + B_F4 : 0, n_ld = HAS3 ? A_F4 + B_F4 : 0;
@@ -198,31 +202,20 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
   IKS_TSTAMP(1)
   IKS_FRAG(ah0, al0, bh0, bl0, 0, 0)
 
-  int cur = 0, kt = 0;
-  for (; kt + 4 < KT; kt += 2) {
+  // Every stage runs the SAME two code bodies (register-set parity): near the end the prefetch index is clamped to the
+  // last tile (a redundant, harmless load + LDS write into a stage nobody reads again) instead of switching to
+  // specialised tail code - cold tail instantiations cost ~1000 cycles each in instruction-cache misses.
+  int cur = 0;
+  for (int kt = 0; kt < KT; kt += 2) {  // KT is even (K % 64 == 0, checked by the launcher)
     int nxt = (cur == 2) ? 0 : cur + 1;
-    k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
+    k_tile(T_{}, T_{}, S1_{}, (kt + 3 < KT ? kt : KT - 4), cur, nxt);
     cur = nxt;
     nxt = (cur == 2) ? 0 : cur + 1;
-    k_tile(T_{}, T_{}, S0_{}, kt + 1, cur, nxt);
+    k_tile(T_{}, T_{}, S0_{}, (kt + 4 < KT ? kt + 1 : KT - 4), cur, nxt);
     cur = nxt;
 #ifdef IKF_TRACE
     if ((kt & 3) == 2 && kt < 128) IKS_TSTAMP(2 + (kt >> 2))
 #endif
-  }
-  for (; kt < KT; ++kt) {
-    const int nxt = (cur == 2) ? 0 : cur + 1;
-    const bool has1 = (kt + 1 < KT), has3 = (kt + 3 < KT);
-    if (kt & 1) {
-      if (has3) k_tile(T_{}, T_{}, S0_{}, kt, cur, nxt);
-      else if (has1) k_tile(T_{}, F_{}, S0_{}, kt, cur, nxt);
-      else k_tile(F_{}, F_{}, S0_{}, kt, cur, nxt);
-    } else {
-      if (has3) k_tile(T_{}, T_{}, S1_{}, kt, cur, nxt);
-      else if (has1) k_tile(T_{}, F_{}, S1_{}, kt, cur, nxt);
-      else k_tile(F_{}, F_{}, S1_{}, kt, cur, nxt);
-    }
-    cur = nxt;
   }
   IKS_TSTAMP(40)
 #undef IKS_GLOAD
@@ -343,7 +336,7 @@ static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
 
 hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
-  if (cfg < 0 || cfg >= kNumSplitCfg || a.N % kSplitBN[cfg] != 0 || a.K % 32 != 0 || a.n_out > 16) return hipErrorInvalidValue;
+  if (cfg < 0 || cfg >= kNumSplitCfg || a.N % kSplitBN[cfg] != 0 || a.K % 64 != 0 || a.K < 128 || a.n_out > 16) return hipErrorInvalidValue;
   switch (cfg) {
     case 0: return epi_red ? launch_sg<true, 0>(a, s) : launch_sg<false, 0>(a, s);
     case 1: return epi_red ? launch_sg<true, 1>(a, s) : launch_sg<false, 1>(a, s);
