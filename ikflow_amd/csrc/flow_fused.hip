@@ -358,7 +358,6 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     }
   };
   using T_ = std::integral_constant<bool, true>;
-  using F_ = std::integral_constant<bool, false>;
 
   // prologue: the (cold) loads of tiles 0, 1 and 2 are issued back to back so their miss latencies overlap
   IKF_TSTAMP(0)

@@ -179,7 +179,6 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
     }
   };
   using T_ = std::integral_constant<bool, true>;
-  using F_ = std::integral_constant<bool, false>;
   using S0_ = std::integral_constant<int, 0>;
   using S1_ = std::integral_constant<int, 1>;
 
