@@ -465,3 +465,72 @@ def test_cabi_status_codes_and_edge_sizes():
 
     with pytest.raises(EngineError, match="coeff_fn_internal_size"):
         Engine(FlowLayout(nb_nodes=2, dim=9, dim_cond=8, width=300, n_hidden=2, clamp=2.5, ndof=7), robot, DEV)
+
+
+def test_hip_path_reproduces_committed_golden_fixtures():
+    """tests/golden/*.npz (made by tests/golden/make_golden.py): BASELINE config 1 inputs (the 3 README poses, batch 16)
+    through the HIP path, both contraction precisions; FK / pose error / LM step fixtures through the kinematics kernels."""
+    import os
+
+    from ikflow_amd.engine import kinematics_engine_for
+    from ikflow_amd.robots import Panda
+
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, model in (("tiny_flow.npz", tiny_model), ("panda_flow.npz", panda_model)):
+        z = np.load(os.path.join(gold, name))
+        robot, hp, lay, sd = model(seed=int(z["weights_seed"]))
+        s = _solver(robot, hp, sd)
+        P, L = torch.from_numpy(z["poses"]).to(DEV), torch.from_numpy(z["latent"]).to(DEV)
+        for prec in ("f32", "f16x3"):
+            s.set_precision(prec)
+            got = s.generate_ik_solutions(P, latent=L).cpu().numpy()
+            assert np.abs(got - z["q_clamped"]).max() <= FLOW_TOL, (name, prec)
+            got_nc = s.generate_ik_solutions(P, latent=L, clamp_to_joint_limits=False).cpu().numpy()
+            assert (np.abs(got_nc - z["q_unclamped"]) / np.maximum(1.0, np.abs(z["q_unclamped"]))).max() <= FLOW_TOL, (name, prec)
+        s.set_precision("f32")
+        if "q_single_pose0" in z.files:  # single-pose form: y = README pose 0, n = 16
+            got1 = s.generate_ik_solutions(P[0].contiguous(), n=16, latent=L).cpu().numpy()
+            assert np.abs(got1 - z["q_single_pose0"]).max() <= FLOW_TOL
+    z = np.load(os.path.join(gold, "panda_kinematics.npz"))
+    robot = Panda()
+    eng = kinematics_engine_for(robot, DEV)
+    fk = eng.forward_kinematics(torch.from_numpy(z["q"]).to(DEV)).cpu().numpy()
+    assert np.abs(fk[:, :3] - z["fk"][:, :3]).max() <= 2e-6
+    assert np.minimum(np.abs(fk[:, 3:] - z["fk"][:, 3:]).max(1), np.abs(fk[:, 3:] + z["fk"][:, 3:]).max(1)).max() <= 2e-6
+    pe, re = eng.pose_error(torch.from_numpy(z["q0"]).to(DEV), torch.from_numpy(z["target"]).to(DEV))
+    assert np.abs(pe.cpu().numpy() - z["pos_err"]).max() <= 2e-6 and np.abs(re.cpu().numpy() - z["rot_err"]).max() <= 3e-5
+    lm = eng.lm_step(torch.from_numpy(z["target"]).to(DEV), torch.from_numpy(z["q0"]).to(DEV)).cpu().numpy()
+    assert np.abs(lm - z["lm_step_f64"]).max() <= 5e-6
+    J = eng.jacobian(torch.from_numpy(z["q"]).to(DEV)).cpu().numpy()
+    assert np.abs(J - z["jac_f64"]).max() <= 3e-6
+
+
+def test_baseline_sizes_size_independent_properties():
+    """BASELINE configs 3 and 4 at full size through properties that need no oracle run."""
+    # config 4: FetchArm, B = 8192 approximate: deterministic, finite, inside limits, oracle on a slice
+    robot, hp, lay, sd = fetch_arm_model()
+    s = _solver(robot, hp, sd)
+    n = 8192
+    _, poses = reachable_poses(robot, n, 40)
+    lat = latents(n, lay.dim, 41)
+    P, L = poses.to(DEV), lat.to(DEV)
+    a = s.generate_ik_solutions(P, latent=L)
+    assert torch.equal(a, s.generate_ik_solutions(P, latent=L)) and bool(torch.isfinite(a).all())
+    lo = torch.tensor([l[0] for l in robot.actuated_joints_limits], device=DEV)
+    hi = torch.tensor([l[1] for l in robot.actuated_joints_limits], device=DEV)
+    assert bool(((a >= lo) & (a <= hi)).all())
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:128], lat[:128])
+    assert (a[:128].cpu() - ref).abs().max().item() <= FLOW_TOL
+    # config 3: Panda exact IK, B = 4096, 1 mm / 0.01 rad: every row reported valid meets the thresholds (checked with the
+    # oracle's FK) and the limits; every other row is exactly 0; valid is a bool vector on the input device
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    _, poses = reachable_poses(robot, 4096, 42)
+    sol, valid = s.generate_exact_ik_solutions(poses.to(DEV), pos_error_threshold=1e-3, rot_error_threshold=0.01)
+    assert sol.shape == (4096, 7) and valid.shape == (4096,) and valid.dtype == torch.bool and sol.device.type == "cuda"
+    sol, valid = sol.cpu(), valid.cpu()
+    assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
+    if int(valid.sum()) > 0:
+        pe, re = ko.calculate_pose_error(robot, sol[valid], poses[valid])
+        assert (pe < 1e-3 * 1.01).all() and (re < 0.01 * 1.01).all()
+        assert torch.equal(sol[valid], ko.clamp_to_joint_limits(robot, sol[valid]))
