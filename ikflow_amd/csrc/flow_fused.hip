@@ -46,6 +46,7 @@ template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WAVES_M
 template <> struct TileCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M = 2, WAVES_N = 4; };
 template <> struct TileCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2; };
 template <> struct TileCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2; };
+template <> struct TileCfg<5> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 2; };  // probe: 4 waves of 64x64
 constexpr int kNumTileCfg = 4;
 static const int kCfgBM[kNumTileCfg] = {128, 64, 64, 32};
 static const int kCfgBN[kNumTileCfg] = {128, 128, 64, 64};
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
   // partial-sum epilogue: one slot = 64 columns for EVERY tile configuration, so the last Linear is summed in the same
   // order whatever the batch size (results are bit-identical across batch sizes)
   constexpr int FKH = BN / 64;
-  static_assert(BN % 64 == 0 && (BM / 32) * FKH <= NT / 64, "not enough waves for the partial-sum epilogue");
+  static_assert(BN % 64 == 0, "the partial-sum epilogue works in 64-column slots");
   constexpr int WM = BM / FWAVES_M, WN = BN / FWAVES_N;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int LDK = BK + 4;
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     __syncthreads();
     constexpr int RB = BM / 32;
     constexpr int CW = 64;  // columns per slot
-    if (wave < RB * FKH) {  // wave-uniform: the remaining waves have no slot
-      const int rb = wave % RB, kh = wave / RB;
+    for (int job = wave; job < RB * FKH; job += NT / 64) {  // wave-uniform: (row block, 64-column slot) jobs over the waves
+      const int rb = job % RB, kh = job / RB;
       floatx16 pacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
@@ -745,6 +746,7 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
 
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
+  if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
   if (cfg == kSkinnyCfg) {
     if (a.N % KBN != 0 || a.K % KBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
     return epi_red ? launch_skinny<true>(a, s) : launch_skinny<false>(a, s);
