@@ -691,12 +691,15 @@ template <bool EPI_RED>
 static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)3 * (KBM + KBN) * (KBK + 4) * sizeof(float);
   auto kern = k_flow_gemm_skinny<EPI_RED>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
+  static bool attr_set[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / KBN);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KNT), smem, s, a);
@@ -731,12 +734,15 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
   constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
   constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (FBK + 4) * sizeof(float);
   auto kern = k_flow_gemm<EPI_RED, CFG>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
+  static bool attr_set[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
   const long long grid = tiles_m * (a.N / TC::BN);

@@ -465,12 +465,15 @@ static hipError_t launch_gemm_p3(const float* A, const float* W, const float* bi
   constexpr int LDK = BK + 4;
   constexpr size_t smem = (size_t)3 * (BM + BN) * LDK * sizeof(float);
   auto kern = k_gemm_lrelu_p3<BM, BN, BK, WAVES_M, WAVES_N>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
+  static bool attr_set[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   const long long tiles_m = (M + BM - 1) / BM;
   const long long grid = tiles_m * (N / BN);
@@ -486,12 +489,15 @@ static hipError_t launch_gemm_t(const float* A, const float* W, const float* bia
   constexpr int LDK = BK + 4;
   constexpr size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   auto kern = k_gemm_lrelu<BM, BN, BK, WAVES_M, WAVES_N>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
+  static bool attr_set[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   const long long tiles_m = (M + BM - 1) / BM;
   const long long grid = tiles_m * (N / BN);

@@ -320,12 +320,15 @@ static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
   using TC = SplitCfg<CFG>;
   constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * 36 * sizeof(float);
   auto kern = k_split_gemm<EPI_RED, CFG>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
+  static bool attr_set[64] = {};
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set[dev_] = true;
   }
   const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
   const long long grid = tiles_m * (a.N / TC::BN);

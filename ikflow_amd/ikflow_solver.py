@@ -244,6 +244,9 @@ class IKFlowSolver:
         """Extension: take the {key: tensor} mapping directly (what pickle.load returns in the reference)."""
         sd = state_dict_to_numpy(state_dict)
         sd = {(k[len("nn_model."):] if k.startswith("nn_model.") else k): v for k, v in sd.items()}
+        sd = {(k[len("_orig_mod."):] if k.startswith("_orig_mod.") else k): v for k, v in sd.items()}  # torch.compile'd modules (:421-427)
+        # older FrEIA releases named the two coupling subnets s1/s2 instead of subnet1/subnet2
+        sd = {k.replace(".s1.", ".subnet1.").replace(".s2.", ".subnet2."): v for k, v in sd.items()}
         validate_state_dict(self._layout, sd)  # RuntimeError like nn.Module.load_state_dict on a bad file
         self._state_dict_np = sd
         if self._engine is not None:
