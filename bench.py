@@ -226,7 +226,7 @@ def main():
         solver.set_precision("f32")
         extra["f16x3_split"] = {
             "value": world * B * n2 / dt2, "unit": "IK solutions/s", "ms_per_step": 1000.0 * dt2 / n2,
-            "kernel": "k_split_gemm", "avg_launch_ms": ms2 / max(nl2, 1),
+            "kernel": "k_split_gemm_dma", "avg_launch_ms": ms2 / max(nl2, 1),
             "max_abs_diff_vs_f32_path": float((sol2 - sol).abs().max().item()),
             "note": "opt-in IKFlowSolver.set_precision('f16x3'): a = hi + lo/2048 operand split, 3 v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate",
         }

@@ -72,22 +72,23 @@ int main(int argc, char** argv) {
     }
   }
   int vsel = argc > 3 ? atoi(argv[3]) : -1;
-  if (vsel == 200) {  // the f16-split contraction (k_split_gemm<false>): correctness vs the fp32 reference, timing, timeline
+  const int scfg = (vsel == 210) ? 10 : 11;
+  if (vsel == 200 || vsel == 210) {  // the f16-split contraction (k_split_gemm<false>): correctness vs the fp32 reference, timing, timeline
     std::vector<uint16_t> sA((size_t)Mp * K * 2), sW((size_t)N * K * 2);
     ikf::split32_pack_host(hA.data(), Mp, K, sA.data()); ikf::split32_pack_host(hW.data(), N, K, sW.data());
     void *dsA, *dsW, *dsC; CK(hipMalloc(&dsA, sA.size() * 2)); CK(hipMalloc(&dsW, sW.size() * 2)); CK(hipMalloc(&dsC, (size_t)Mp * N * 4));
     CK(hipMemcpy(dsA, sA.data(), sA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dsW, sW.data(), sW.size() * 2, hipMemcpyHostToDevice));
     ikf::SplitGemmArgs g{}; g.A = dsA; g.W = dsW; g.bias = b; g.C = dsC; g.M = M; g.N = N; g.K = K; g.slope = 0.01f;
-    CK(ikf::launch_split_gemm(false, 0, g, 0)); CK(hipDeviceSynchronize());
+    CK(ikf::launch_split_gemm(false, scfg, g, 0)); CK(hipDeviceSynchronize());
     std::vector<uint16_t> sC((size_t)Mp * N * 2); CK(hipMemcpy(sC.data(), dsC, sC.size() * 2, hipMemcpyDeviceToHost));
     double maxerr = 0;
     for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
       _Float16 hi, lo; __builtin_memcpy(&hi, &sC[(size_t)m * N * 2 + (size_t)(n >> 5) * 64 + (n & 31)], 2); __builtin_memcpy(&lo, &sC[(size_t)m * N * 2 + (size_t)(n >> 5) * 64 + 32 + (n & 31)], 2);
       maxerr = fmax(maxerr, fabs((double)(float)hi + (double)(float)lo / 2048.0 - hR[(size_t)m * N + n])); }
     for (int rep = 0; rep < 3; ++rep) {
-      for (int i = 0; i < 10; ++i) ikf::launch_split_gemm(false, 0, g, 0);
+      for (int i = 0; i < 10; ++i) ikf::launch_split_gemm(false, scfg, g, 0);
       CK(hipEventRecord(e0, 0));
-      for (int i = 0; i < iters; ++i) ikf::launch_split_gemm(false, 0, g, 0);
+      for (int i = 0; i < iters; ++i) ikf::launch_split_gemm(false, scfg, g, 0);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       printf("k_split_gemm M=%d K=%d: %.2f us/launch  %.1f TFLOP/s (algorithmic)  maxerr vs f32 ref %.2e\n", M, K, 1000.0 * ms / iters, flop / (ms / iters * 1e-3) / 1e12, maxerr);
@@ -95,7 +96,7 @@ int main(int argc, char** argv) {
     unsigned long long* tb; const int nb = 4096;
     CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
-    ikf::launch_split_gemm(false, 0, g, 0); ikf::launch_split_gemm(false, 0, g, 0);
+    ikf::launch_split_gemm(false, scfg, g, 0); ikf::launch_split_gemm(false, scfg, g, 0);
     CK(hipDeviceSynchronize());
     std::vector<unsigned long long> ht((size_t)nb * 64);
     CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
