@@ -132,6 +132,16 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * ER;
   const int M = e.M, D = e.D;
+  // this thread's slice of the first Linear (first column group) is fetched up front: its L2 latency hides behind the
+  // pending-coupling phases below
+  const int n4 = e.width >> 2;
+  floatx4 w0[IN], b0;
+  {
+    const int c4 = t < n4 ? t : 0;
+#pragma unroll
+    for (int k = 0; k < IN; ++k) w0[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
+    b0 = reinterpret_cast<const floatx4*>(e.b1)[c4];
+  }
   finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, aa, so, sn, t);
   for (int idx = t; idx < ER * D; idx += NT) {
     const int r = idx / D, d = idx - r * D;
@@ -153,12 +163,18 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     U[r * ROWBUF + k] = v;
   }
   __syncthreads();
-  const int n4 = e.width >> 2;
   for (int c4 = t; c4 < n4; c4 += NT) {
     floatx4 w[IN];
+    floatx4 b;
+    if (c4 == t) {
 #pragma unroll
-    for (int k = 0; k < IN; ++k) w[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
-    floatx4 b = reinterpret_cast<const floatx4*>(e.b1)[c4];
+      for (int k = 0; k < IN; ++k) w[k] = w0[k];
+      b = b0;
+    } else {
+#pragma unroll
+      for (int k = 0; k < IN; ++k) w[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
+      b = reinterpret_cast<const floatx4*>(e.b1)[c4];
+    }
     if (e.ps.softflow != 0.0f) b += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft)[c4];
 #pragma unroll 4
     for (int r = 0; r < ER; ++r) {
