@@ -52,72 +52,49 @@ static const int kCfgBM[kNumTileCfg] = {128, 64, 64, 32};
 static const int kCfgBN[kNumTileCfg] = {128, 128, 64, 64};
 
 // ---------------------------------------------------------------------------------------------------------------
-// Finish a pending coupling for R rows starting at m0 and leave the new state rows in LDS sn[R][ROWBUF].
-// aa, so, sn: LDS arrays of R*ROWBUF floats.  All NT threads participate; ends with a barrier.
+// Finish a pending coupling for R rows starting at m0: one thread per (row, state element) sums that element's (s, t)
+// partial-sum slots in fixed order, applies  s = clamp*(0.636*atan s),  y = (x - t)*exp(-s)  and leaves the row
+// [y1 | x2] / [x1 | y2] ("cat", BEFORE PermuteRandom^-1) in LDS cat[R][ROWBUF].  The permutation is applied by the
+// reader through state_src(): new_state[d] = cat[state_src(pc, d)].  Ends with a barrier.
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int state_src(const PendingCoupling& pc, int d) {
+  return (pc.P != nullptr && pc.which == 2) ? pc.perm_inv[d] : d;  // PermuteRandom rev: out[:, d] = cat[:, perm_inv[d]]
+}
+
 template <int NT, int R>
 __device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const float* __restrict__ x_src,
-                                                    int D, int L1, float clamp, int m0, int M, float* aa, float* so,
-                                                    float* sn, int t) {
+                                                    int D, int L1, float clamp, int m0, int M, float* cat, int t) {
   const int L2 = D - L1;
-  for (int idx = t; idx < R * D; idx += NT) {
-    const int r = idx / D, d = idx - r * D;
-    int gr = m0 + r;
-    gr = gr < M ? gr : M - 1;
-    so[r * ROWBUF + d] = x_src[(size_t)gr * D + d];
-  }
-  if (pc.P != nullptr) {
-    for (int idx = t; idx < R * pc.n_out; idx += NT) {
-      const int r = idx / pc.n_out, j = idx - r * pc.n_out;
-      const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + j;  // P rows are padded to the tile: no clamp needed
-      float a = pc.b_last[j];
-      for (int s0 = 0; s0 < pc.slots; s0 += 16) {  // 16 independent loads in flight, then a fixed-order sum
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = (s0 + q < pc.slots) ? p[(size_t)(s0 + q) * pc.slot_stride] : 0.f;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a += v[q];
-      }
-      aa[r * ROWBUF + j] = a;
-    }
-  }
-  __syncthreads();
-  if (pc.P == nullptr) {
-    for (int idx = t; idx < R * D; idx += NT) {
-      const int r = idx / D, d = idx - r * D;
-      sn[r * ROWBUF + d] = so[r * ROWBUF + d];
-    }
-    __syncthreads();
-    return;
-  }
-  // which == 1: y2 = (x2 - t1) * exp(-s1), x1 untouched.   which == 2: y1 = (x1 - t2) * exp(-s2), then perm_inv gather
+  // which == 1: y2 = (x2 - t1) * exp(-s1), x1 untouched.   which == 2: y1 = (x1 - t2) * exp(-s2), x2 (= y2) untouched
   const int nl = (pc.which == 1) ? L2 : L1;
   const int off = (pc.which == 1) ? L1 : 0;
-  for (int idx = t; idx < R * D; idx += NT) {
-    const int r = idx / D, d = idx - r * D;
-    float v = so[r * ROWBUF + d];
-    if (d >= off && d < off + nl) {
+  for (int idx = t; idx < R * ROWBUF; idx += NT) {
+    const int r = idx / ROWBUF, d = idx % ROWBUF;  // ROWBUF is a power of two: shifts
+    if (d >= D) continue;
+    int gr = m0 + r;
+    gr = gr < M ? gr : M - 1;
+    float v = x_src[(size_t)gr * D + d];
+    if (pc.P != nullptr && d >= off && d < off + nl) {
       const int j = d - off;
-      const float sv = aa[r * ROWBUF + j], tv = aa[r * ROWBUF + nl + j];
+      const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE;  // P rows are padded to the tile: no clamp needed
+      float sv = pc.b_last[j], tv = pc.b_last[nl + j];
+      for (int s0 = 0; s0 < pc.slots; s0 += 16) {  // 32 independent loads in flight, then fixed-order sums
+        float a[16], b[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const bool ok = s0 + q < pc.slots;
+          a[q] = ok ? p[(size_t)(s0 + q) * pc.slot_stride + j] : 0.f;
+          b[q] = ok ? p[(size_t)(s0 + q) * pc.slot_stride + nl + j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { sv += a[q]; tv += b[q]; }
+      }
       const float s_cl = clamp * (0.636f * atanf(sv));
       v = (v - tv) * expf(-s_cl);
     }
-    sn[r * ROWBUF + d] = v;
+    cat[r * ROWBUF + d] = v;
   }
   __syncthreads();
-  if (pc.which == 2) {
-    // PermuteRandom rev: out[:, d] = cat[:, perm_inv[d]]  (ikflow/model.py:339)
-    for (int idx = t; idx < R * D; idx += NT) {
-      const int r = idx / D, d = idx - r * D;
-      so[r * ROWBUF + d] = sn[r * ROWBUF + pc.perm_inv[d]];
-    }
-    __syncthreads();
-    for (int idx = t; idx < R * D; idx += NT) {
-      const int r = idx / D, d = idx - r * D;
-      sn[r * ROWBUF + d] = so[r * ROWBUF + d];
-    }
-    __syncthreads();
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -128,12 +105,12 @@ constexpr int ER = 16;
 template <int IN>
 __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   constexpr int NT = 256;
-  __shared__ __attribute__((aligned(16))) float aa[ER * ROWBUF], so[ER * ROWBUF], sn[ER * ROWBUF], U[ER * ROWBUF];
+  __shared__ __attribute__((aligned(16))) float cat[ER * ROWBUF], U[ER * ROWBUF];
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * ER;
   const int M = e.M, D = e.D;
   // this thread's slice of the first Linear (first column group) is fetched up front: its L2 latency hides behind the
-  // pending-coupling phases below
+  // pending-coupling phase below
   const int n4 = e.width >> 2;
   floatx4 w0[IN], b0;
   {
@@ -142,27 +119,27 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     for (int k = 0; k < IN; ++k) w0[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
     b0 = reinterpret_cast<const floatx4*>(e.b1)[c4];
   }
-  finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, aa, so, sn, t);
-  for (int idx = t; idx < ER * D; idx += NT) {
-    const int r = idx / D, d = idx - r * D;
-    if (m0 + r < M) e.x_dst[(size_t)(m0 + r) * D + d] = sn[r * ROWBUF + d];
+  // one thread per (row, column) of the 16-wide input row; the pose element is fetched before the pending phase
+  static_assert(ER * ROWBUF == NT, "entry kernel maps one thread to one (row, input column)");
+  const int ur = t / ROWBUF, uk = t % ROWBUF;
+  float pose_v = 0.f;
+  if (uk >= e.n_x && uk < IN) {
+    int gr = m0 + ur;
+    gr = gr < M ? gr : M - 1;
+    const long long grow = e.row0 + gr;
+    // one pose per row (n_mod == rows) and the single-pose broadcast (n_mod == 1) skip the 64-bit modulo
+    const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
+    const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
+    pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
   }
-  for (int idx = t; idx < ER * IN; idx += NT) {
-    const int r = idx / IN, k = idx - r * IN;
-    float v;
-    if (k < e.n_x) {
-      v = sn[r * ROWBUF + e.x_off + k];
-    } else {
-      int gr = m0 + r;
-      gr = gr < M ? gr : M - 1;
-      const long long grow = e.row0 + gr;
-      const long long pm = grow % e.ps.n_mod;
-      const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
-      v = e.ps.poses[pi * e.ps.stride + (k - e.n_x)];
-    }
-    U[r * ROWBUF + k] = v;
-  }
+  IKF_TSTAMP(0)
+  finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, cat, t);
+  IKF_TSTAMP(1)
+  // publish the new state and assemble u = [x_part, pose, 0-pad]
+  if (uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
+  U[ur * ROWBUF + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;
   __syncthreads();
+  IKF_TSTAMP(2)
   for (int c4 = t; c4 < n4; c4 += NT) {
     floatx4 w[IN];
     floatx4 b;
@@ -178,15 +155,16 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     if (e.ps.softflow != 0.0f) b += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft)[c4];
 #pragma unroll 4
     for (int r = 0; r < ER; ++r) {
+      // the row's 16 inputs as four LDS broadcast reads (same address in every lane)
+      float u[ROWBUF];
+#pragma unroll
+      for (int q = 0; q < ROWBUF / 4; ++q) {
+        const floatx4 uq = *reinterpret_cast<const floatx4*>(U + r * ROWBUF + q * 4);
+        u[q * 4 + 0] = uq.x; u[q * 4 + 1] = uq.y; u[q * 4 + 2] = uq.z; u[q * 4 + 3] = uq.w;
+      }
       floatx4 acc = b;
 #pragma unroll
-      for (int k = 0; k < IN; ++k) {
-        const float u = U[r * ROWBUF + k];  // same address in every lane: LDS broadcast
-        acc.x = fmaf(u, w[k].x, acc.x);
-        acc.y = fmaf(u, w[k].y, acc.y);
-        acc.z = fmaf(u, w[k].z, acc.z);
-        acc.w = fmaf(u, w[k].w, acc.w);
-      }
+      for (int k = 0; k < IN; ++k) acc += u[k] * w[k];
       acc.x = acc.x > 0.f ? acc.x : acc.x * e.slope;
       acc.y = acc.y > 0.f ? acc.y : acc.y * e.slope;
       acc.z = acc.z > 0.f ? acc.z : acc.z * e.slope;
@@ -209,6 +187,7 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
       }
     }
   }
+  IKF_TSTAMP(3)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -500,19 +479,19 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
-  constexpr int R = 128, NT = 256;
-  __shared__ float aa[R * ROWBUF], so[R * ROWBUF], sn[R * ROWBUF];
+  constexpr int R = 32, NT = 256;
+  __shared__ float cat[R * ROWBUF];
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * R;
-  finish_pending_rows<NT, R>(f.pend, f.x_src, f.D, f.L1, f.clamp, m0, f.M, aa, so, sn, t);
+  finish_pending_rows<NT, R>(f.pend, f.x_src, f.D, f.L1, f.clamp, m0, f.M, cat, t);
   // FixedLinearTransform rev: (x - b).mm(M_inv); [:, :ndof]; clamp_to_joint_limits
   const int D = f.D;
-  for (int idx = t; idx < R * f.ndof; idx += NT) {
-    const int r = idx / f.ndof, j = idx - r * f.ndof;
-    if (m0 + r >= f.M) continue;
+  for (int idx = t; idx < R * ROWBUF; idx += NT) {
+    const int r = idx / ROWBUF, j = idx % ROWBUF;
+    if (j >= f.ndof || m0 + r >= f.M) continue;
     float q = 0.f;
     for (int k = 0; k < D; ++k) {
-      float xv = sn[r * ROWBUF + k];
+      float xv = cat[r * ROWBUF + state_src(f.pend, k)];
       if (f.sigmoid) xv = 1.0f / (1.0f + expf(-xv));  // InvertibleSigmoidFlipped rev (ikflow/model.py:124-127)
       q = fmaf(xv - f.b_lin[k], f.M_inv[k * D + j], q);
     }
@@ -799,7 +778,7 @@ hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s) {
 
 hipError_t launch_flow_finalize(const FinalizeArgs& f, hipStream_t s) {
   if (f.M <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_flow_finalize, dim3((unsigned)((f.M + 127) / 128)), dim3(256), 0, s, f);
+  hipLaunchKernelGGL(k_flow_finalize, dim3((unsigned)((f.M + 31) / 32)), dim3(256), 0, s, f);
   return hipGetLastError();
 }
 

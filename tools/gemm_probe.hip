@@ -72,6 +72,35 @@ int main(int argc, char** argv) {
     }
   }
   int vsel = argc > 3 ? atoi(argv[3]) : -1;
+  if (vsel == 300) {  // k_subnet_entry<11> timeline: pending coupling (16 slots) + first Linear, rows = M
+    const int D = 7, W1 = 1024, IN = 11;
+    float *x, *x2, *P, *w1t, *b1, *bl, *h; int* perm;
+    CK(hipMalloc(&x, (size_t)M * D * 4)); CK(hipMalloc(&x2, (size_t)M * D * 4)); CK(hipMalloc(&P, (size_t)16 * Mp * 16 * 4));
+    CK(hipMalloc(&w1t, (size_t)IN * W1 * 4)); CK(hipMalloc(&b1, W1 * 4)); CK(hipMalloc(&bl, 64)); CK(hipMalloc(&h, (size_t)Mp * W1 * 4)); CK(hipMalloc(&perm, 64));
+    CK(hipMemset(x, 0, (size_t)M * D * 4)); CK(hipMemset(P, 0, (size_t)16 * Mp * 16 * 4)); CK(hipMemset(bl, 0, 64));
+    CK(hipMemcpy(w1t, hW.data(), (size_t)IN * W1 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(b1, hb.data(), W1 * 4, hipMemcpyHostToDevice));
+    int hperm[7] = {6, 2, 1, 3, 0, 5, 4}; CK(hipMemcpy(perm, hperm, 28, hipMemcpyHostToDevice));
+    ikf::EntryArgs e{}; e.pend.P = P; e.pend.b_last = bl; e.pend.perm_inv = perm; e.pend.slot_stride = (long long)Mp * 16; e.pend.slots = 16; e.pend.which = 2; e.pend.n_out = 6;
+    e.x_src = x; e.x_dst = x2; e.M = M; e.D = D; e.L1 = 3; e.clamp = 2.5f; e.x_off = 0; e.n_x = 3;
+    e.ps.poses = A; e.ps.idx = nullptr; e.ps.n_mod = M; e.ps.stride = 7; e.ps.softflow = 0.f; e.row0 = 0;
+    e.w1t = w1t; e.w1soft = b1; e.b1 = b1; e.width = W1; e.slope = 0.01f; e.h_out = h; e.split_out = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+      for (int i = 0; i < 10; ++i) ikf::launch_subnet_entry(IN - 0, e, 0);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) ikf::launch_subnet_entry(IN, e, 0);
+      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("k_subnet_entry<11> M=%d: %.2f us/launch\n", M, 1000.0 * ms / iters);
+    }
+    unsigned long long* tb; const int nb = 4096;
+    CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
+    ikf::launch_subnet_entry(IN, e, 0); ikf::launch_subnet_entry(IN, e, 0); CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> ht((size_t)nb * 64); CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+    for (int bI : {0, 100, 200}) { const unsigned long long* r = &ht[(size_t)bI * 64];
+      printf("block %3d: pending %llu  publish+U %llu  first-Linear+store %llu  total %llu cycles\n", bI, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[3] - r[0]); }
+    return 0;
+  }
   const int scfg = (vsel == 210) ? 10 : 11;
   if (vsel == 200 || vsel == 210) {  // the f16-split contraction (k_split_gemm<false>): correctness vs the fp32 reference, timing, timeline
     std::vector<uint16_t> sA((size_t)Mp * K * 2), sW((size_t)N * K * 2);
