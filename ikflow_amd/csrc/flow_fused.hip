@@ -501,75 +501,100 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Small batches (rows <= 512): the 32x32 f32 MFMA block of one wave over K = 1024 is 512 dependent-issue MFMAs =
-// 32768 cycles whatever the tile, so the launch is latency-bound (16 us) and half the SIMDs idle.  This form splits K
-// INSIDE the workgroup: tile 32x64, BK = 128 per stage, 8 waves = 2 column halves x 4 k-quarters; every wave issues 16
-// MFMAs per stage (128 per launch), two stages, one barrier per stage; the four k-quarter partial blocks are summed
-// through LDS in fixed order kq = 0,1,2,3.  (The quarter split changes the summation order with respect to the large
-// tiles: results agree to rounding, not bit for bit, across the 1024-row boundary.)
+// Small batches (rows <= 512): at most 256 tiles of 32x64 exist, one per CU, and the launch is a latency chain, not a
+// throughput problem.  This form splits K INSIDE the workgroup: tile 32x64, BK = 128 per stage, 16 waves = 2 column
+// halves x 8 k-slices (four waves per SIMD); every wave issues 8 MFMAs per stage.  What the measurements said
+// (tools/gemm_probe.hip 104, per-stage cost against the 2048-cycle MFMA floor):
+//   * every VMEM wave-instruction issued with 64-bit VGPR addresses costs its SIMD ~70 cycles of matrix-pipe time;
+//     buffer loads (SGPR descriptor + loop-invariant VGPR offset + scalar tile offset) cost about a third of that and
+//     leave no address arithmetic in the loop: 3000 -> 2450 cycles per stage;
+//   * each W element feeds exactly one wave, so W skips LDS and is fetched as fragments from a fragment-major image
+//     (k_wfrag_pack; from the row-major weight the same fetch is 32 rows 4 KB apart = one L2 channel: 5200-cycle
+//     prologue); only the A rows are staged through LDS (two stages, one barrier per stage);
+//   * the loop is branch-free (clamped prefetch index): with conditional loads the compiler waits vmcnt(0).
+// The k-slice partial blocks are summed through LDS in fixed order kq = 0..7 by all 16 waves (two accumulator
+// registers each).  (The slice split changes the summation order with respect to the large tiles: results agree to
+// rounding, not bit for bit, across the 512-row boundary.)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int KBM = 32, KBN = 64, KBK = 128, KNT = 512;
+constexpr int KBM = 32, KBN = 64, KBK = 128;
+constexpr int KKS = 8;               // k-slices per tile (waves = 2 column halves x KKS)
+constexpr int KNT = 2 * KKS * 64;    // 1024 threads: four waves per SIMD
+constexpr int KKW = KBK / KKS;       // k per wave per tile (16)
+constexpr int KKG = KKW / 8;         // MFMA groups (8 k = 4 MFMAs) per wave per tile (2)
+// LDS: two A stages in the loop; afterwards the KKS partial blocks + the epilogue's T / w_last tiles
+constexpr size_t kSkinnyLds = sizeof(float) * ((size_t)KKS * 2 * 16 * 64 + (size_t)(KBM + 32) * (KBN + 4));
 
 template <bool EPI_RED>
 __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
-  constexpr int BM = KBM, BN = KBN, BK = KBK, NT = KNT;
+  constexpr int BM = KBM, BN = KBN, BK = KBK, NT = KNT, KS = KKS;
   constexpr int LDK = BK + 4;
-  constexpr int KQ4 = BK / 4;                 // float4 per tile row
-  constexpr int NF4 = (BM + BN) * KQ4 / NT;   // float4 per thread per stage (A rows first, then W rows)
-  constexpr int STAGE = (BM + BN) * LDK;
+  constexpr int KQ4 = BK / 4;           // float4 per tile row
+  constexpr int NFA = BM * KQ4 / NT;    // float4 of the A tile per thread per stage
+  constexpr int STAGE = BM * LDK;       // only A rows are staged through LDS
   constexpr int LDT = BN + 4;
-  static_assert((BM + BN) * KQ4 % NT == 0, "tile/threads mismatch");
-  static_assert(3 * STAGE >= 3 * 2 * 16 * 64 && 3 * STAGE >= (BM + 32) * LDT, "reduction/epilogue scratch must fit");
+  static_assert(BM * KQ4 % NT == 0 && NFA >= 1, "tile/threads mismatch");
+  static_assert(KKG == 2, "the iteration below is written for two MFMA groups per wave per tile");
+  static_assert(kSkinnyLds >= sizeof(float) * 2 * STAGE, "the two A stages must fit");
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][BM + BN][LDK]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BM][LDK] / reduction scratch
 
   const int M = g.M, N = g.N, K = g.K;
   const int tiles_n = N / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // wave id as a scalar
   const int nh = wave & 1, kq = wave >> 1;
 
   floatx16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  // staging: float4 f = t + i*NT of the stage image; rows 0..BM-1 are A rows, BM.. are W rows
-  const float* src[NF4];
-  int ldst[NF4];
+  // A rows go through LDS (both column halves read them).  Every W element is used by exactly one wave, so the W
+  // fragments skip LDS: each lane fetches its own float4 (row n0 + nh*32 + lane%32, k-slice kq, 4 k per MFMA group)
+  // straight into registers two tiles ahead, from the fragment-major image (k_wfrag_pack) where a wave's fetch is
+  // one contiguous 1 KB burst (32 rows 4 KB apart in the row-major weight all land on one L2 channel).
+  // Addresses are (scalar base) + (loop-invariant 32-bit lane offset): the loop carries no vector address arithmetic -
+  // every VALU instruction issued between MFMAs delays the matrix pipe of this latency-bound kernel.
+  unsigned aoff[NFA];  // byte offset of this thread's float4 in the A operand (tile 0)
+  int ldst[NFA];
 #pragma unroll
-  for (int i = 0; i < NF4; ++i) {
+  for (int i = 0; i < NFA; ++i) {
     const int f = t + i * NT, row = f / KQ4, c4 = f - row * KQ4;
-    if (row < BM) {
-      int gr = m0 + row;
-      gr = gr < M ? gr : M - 1;
-      src[i] = g.A + (size_t)gr * K + c4 * 4;
-    } else {
-      src[i] = g.W + (size_t)(n0 + row - BM) * K + c4 * 4;
-    }
+    int gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    aoff[i] = ((unsigned)gr * (unsigned)K + c4 * 4) * 4u;
     ldst[i] = row * LDK + c4 * 4;
   }
-  const int fragA = (lane & 31) * LDK + kq * 32 + (lane >> 5) * 4;
-  const int fragB = (BM + nh * 32 + (lane & 31)) * LDK + kq * 32 + (lane >> 5) * 4;
+  constexpr int WTILE = 2 * KS * KKG * 256;  // floats per (column tile, k tile) = 64 x 128
   const int KT = K / BK;
+  // buffer loads: (SGPR descriptor) + (loop-invariant 32-bit VGPR offset) + (scalar tile offset)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
+  const unsigned wtile0 = (unsigned)tn * KT;                                     // (column tile, k tile 0)
+  const unsigned woff = (unsigned)((kq * 2 + nh) * (KKG * 256) * 4) + lane * 16u;  // wave's slice + lane, bytes
+  const int fragA = (lane & 31) * LDK + kq * KKW + (lane >> 5) * 4;
+#define IKK_LDA(i, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[i], __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
+#define IKK_LDW(kk, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff + (kk) * 1024, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
 
-  floatx4 rg[NF4];
+  IKF_TSTAMP(0)
+  floatx4 rg[NFA], w0[KKG], w1[KKG];
 #pragma unroll
-  for (int i = 0; i < NF4; ++i) rg[i] = *reinterpret_cast<const floatx4*>(src[i]);
+  for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, 0);
 #pragma unroll
-  for (int i = 0; i < NF4; ++i) *reinterpret_cast<floatx4*>(smem + ldst[i]) = rg[i];
-  if (KT > 1) {
+  for (int kk = 0; kk < KKG; ++kk) w0[kk] = IKK_LDW(kk, 0);
 #pragma unroll
-    for (int i = 0; i < NF4; ++i) rg[i] = *reinterpret_cast<const floatx4*>(src[i] + BK);
+  for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + ldst[i]) = rg[i];
+  {
+    const int k1 = KT > 1 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k1);
+#pragma unroll
+    for (int kk = 0; kk < KKG; ++kk) w1[kk] = IKK_LDW(kk, k1);
   }
   __syncthreads();
 
-#define IKK_FRAG(FA, FB, stage, kk)                                                       \
-  {                                                                                       \
-    FA = *reinterpret_cast<const floatx4*>(smem + (stage) * STAGE + fragA + (kk) * 8);    \
-    FB = *reinterpret_cast<const floatx4*>(smem + (stage) * STAGE + fragB + (kk) * 8);    \
-  }
+#define IKK_FRAG(FA, stage, kk) FA = *reinterpret_cast<const floatx4*>(smem + (stage) * STAGE + fragA + (kk) * 8);
 #define IKK_MFMA(FA, FB)                                                                  \
   {                                                                                       \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.x, FB.x, acc, 0, 0, 0);                 \
@@ -577,78 +602,91 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.z, FB.z, acc, 0, 0, 0);                 \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.w, FB.w, acc, 0, 0, 0);                 \
   }
-  // 3 stages, one barrier per stage placed mid-stage (same hazard argument as k_flow_gemm): tile kt+1 is written into
-  // stage (kt+1)%3 during the first half of stage kt, the next fragments are always read one k-group ahead
-  floatx4 fa0, fb0, fa1, fb1;
-  IKK_FRAG(fa0, fb0, 0, 0)
-  int cur = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    const int nxt = (cur == 2) ? 0 : cur + 1;
-    const bool has1 = (kt + 1 < KT), has2 = (kt + 2 < KT);
-    IKK_FRAG(fa1, fb1, cur, 1)
-    IKK_MFMA(fa0, fb0)
-    if (has1) {
-      float* nx = smem + nxt * STAGE;
-#pragma unroll
-      for (int i = 0; i < NF4; ++i) *reinterpret_cast<floatx4*>(nx + ldst[i]) = rg[i];
-    }
-    if (has2) {
-#pragma unroll
-      for (int i = 0; i < NF4; ++i) rg[i] = *reinterpret_cast<const floatx4*>(src[i] + (kt + 2) * BK);
-    }
-    IKK_FRAG(fa0, fb0, cur, 2)
-    IKK_MFMA(fa1, fb1)
-    __syncthreads();
-    IKK_FRAG(fa1, fb1, cur, 3)
-    IKK_MFMA(fa0, fb0)
-    if (has1) IKK_FRAG(fa0, fb0, nxt, 0)
-    IKK_MFMA(fa1, fb1)
-    cur = nxt;
+  // The loop body is branch-free: prefetches past the last tile re-read the last tile (clamped index) and the extra
+  // LDS image is never consumed.  With conditional loads the compiler cannot count outstanding loads across the back
+  // edge and falls back to s_waitcnt vmcnt(0) in front of the MFMAs, i.e. a full memory round trip per iteration.
+#define IKK_WLOAD(WC, kk) WC[kk] = IKK_LDW(kk, k2);
+  // One barrier per tile, two LDS stages: A tile kt+1 is written into the other stage at the top of iteration kt (all
+  // its readers - iteration kt-1 - finished before the barrier of iteration kt-1) and its first fragment is fetched
+  // behind the barrier.  WC holds the W fragments of tile kt, WN those of tile kt+1; each WC[kk] is refilled with tile
+  // kt+2 as soon as its MFMA group has issued.  The loop is unrolled by two so both the stage index and the register
+  // set are compile-time: every LDS address is an immediate offset.  Four waves share a SIMD, so while one of them
+  // issues its loads / LDS traffic the other three keep the matrix pipe fed.
+#define IKK_ITER(WC, WN, CUR, NXT)                                                        \
+  {                                                                                       \
+    const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;                                       \
+    IKK_FRAG(fa1, CUR, 1)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; \
+    _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k2);               \
+    IKK_PIN                                                                               \
+    IKK_MFMA(fa0, WC[0])                                                                  \
+    IKK_WLOAD(WC, 0)                                                                      \
+    IKK_PIN                                                                               \
+    __syncthreads();                                                                      \
+    IKK_FRAG(fa0, NXT, 0)                                                                 \
+    IKK_PIN                                                                               \
+    IKK_MFMA(fa1, WC[1])                                                                  \
+    IKK_WLOAD(WC, 1)                                                                      \
+    IKK_PIN                                                                               \
+    IKK_STAMP                                                                             \
+    ++kt;                                                                                 \
   }
+#define IKK_PIN __builtin_amdgcn_sched_barrier(0);  // keep the hand-placed load / LDS / MFMA order
+#ifdef IKF_TRACE
+#define IKK_STAMP if (kt < 32) IKF_TSTAMP(2 + kt)
+#else
+#define IKK_STAMP
+#endif
+  floatx4 fa0, fa1;
+  IKK_FRAG(fa0, 0, 0)
+  IKF_TSTAMP(1)
+  for (int kt = 0; kt < KT;) {  // KT is even (launcher: K % (2*BK) == 0)
+    IKK_ITER(w0, w1, 0, 1)
+    IKK_ITER(w1, w0, 1, 0)
+  }
+#undef IKK_ITER
+#undef IKK_PIN
+#undef IKK_STAMP
+#undef IKK_WLOAD
 #undef IKK_FRAG
 #undef IKK_MFMA
+#undef IKK_LDA
+#undef IKK_LDW
   __syncthreads();  // all fragment reads done before the stage area is reused
+  IKF_TSTAMP(40)
 
-  // ---- sum the four k-quarter partial blocks (fixed order) in the waves of quarter 0
-  float* red = smem;  // [3][2][16][64]
-  if (kq > 0) {
+  // ---- sum the k-slice partial blocks in fixed order kq = 0, 1, ..: every wave parks its block in LDS, then wave
+  // (kq, nh) finishes accumulator registers 2*kq and 2*kq+1 (two output rows per lane half) of column half nh
+  float* red = smem;  // [KS][2][16][64]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[(((kq - 1) * 2 + nh) * 16 + r) * 64 + lane] = acc[r];
-  }
+  for (int r = 0; r < 16; ++r) red[((kq * 2 + nh) * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
-  if (kq == 0) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += red[((q * 2 + nh) * 16 + r) * 64 + lane];
-  }
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
-  if constexpr (!EPI_RED) {
-    if (kq == 0) {
-      const int col = n0 + nh * 32 + col_l;
-      const float bv = g.bias[col];
+  float fin[2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
-        float v = acc[r] + bv;
-        v = v > 0.f ? v : v * g.slope;
-        g.C[(size_t)row * N + col] = v;  // row-padded buffer: unpredicated
-      }
+  for (int j = 0; j < 2; ++j) {
+    const int r = 2 * kq + j;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) v += red[((q * 2 + nh) * 16 + r) * 64 + lane];
+    v += g.bias[n0 + nh * 32 + col_l];
+    fin[j] = v > 0.f ? v : v * g.slope;
+  }
+  if constexpr (!EPI_RED) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * kq + j;
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
+      g.C[(size_t)row * N + n0 + nh * 32 + col_l] = fin[j];  // row-padded buffer: unpredicated
     }
   } else {
-    __syncthreads();  // red[] fully consumed before T/Wl overwrite it
-    float* T = smem;
-    float* Wl = smem + BM * LDT;
-    if (kq == 0) {
-      const int cl = nh * 32 + col_l;
-      const float bv = g.bias[n0 + cl];
+    float* T = smem + KS * 2 * 16 * 64;  // behind red[] (other waves may still be summing)
+    float* Wl = T + BM * LDT;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + row_h;
-        float v = acc[r] + bv;
-        v = v > 0.f ? v : v * g.slope;
-        T[rl * LDT + cl] = v;
-      }
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * kq + j;
+      const int rl = (r & 3) + 8 * (r >> 2) + row_h;
+      T[rl * LDT + nh * 32 + col_l] = fin[j];
     }
     for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
       const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
@@ -680,11 +718,37 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
       }
     }
   }
+  IKF_TSTAMP(41)
+}
+
+// fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
+//   ((((tn*KT + kt)*KKS + kq)*2 + nh)*KKG + kk)*64 + lane
+//        <-  W[tn*64 + nh*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
+__global__ __launch_bounds__(256) void k_wfrag_pack(const float* __restrict__ W, float* __restrict__ out, int N, int K) {
+  const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= (size_t)N * K / 4) return;
+  const int KT = K / KBK;
+  const int lane = (int)(f & 63);
+  size_t r = f >> 6;
+  const int kk = (int)(r % KKG); r /= KKG;
+  const int nh = (int)(r & 1); r >>= 1;
+  const int kq = (int)(r % KKS); r /= KKS;
+  const int kt = (int)(r % KT);
+  const int tn = (int)(r / KT);
+  const size_t row = (size_t)tn * KBN + nh * 32 + (lane & 31);
+  const int k = kt * KBK + kq * KKW + kk * 8 + (lane >> 5) * 4;
+  reinterpret_cast<floatx4*>(out)[f] = *reinterpret_cast<const floatx4*>(W + row * K + k);
+}
+hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream_t s) {
+  if (N % KBN != 0 || K % KBK != 0) return hipErrorInvalidValue;
+  const size_t n4 = (size_t)N * K / 4;
+  hipLaunchKernelGGL(k_wfrag_pack, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W, out, N, K);
+  return hipGetLastError();
 }
 
 template <bool EPI_RED>
 static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = (size_t)3 * (KBM + KBN) * (KBK + 4) * sizeof(float);
+  constexpr size_t smem = kSkinnyLds;
   auto kern = k_flow_gemm_skinny<EPI_RED>;
   // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
   static bool attr_set[64] = {};
@@ -703,8 +767,9 @@ static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSkinnyCfg = 4;  // k_flow_gemm_skinny
+int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_pick_cfg(long long rows, int width) {
-  if (rows <= 512 && width % KBN == 0 && width % KBK == 0) return kSkinnyCfg;
+  if (rows <= 512 && width % KBN == 0 && width % (2 * KBK) == 0) return kSkinnyCfg;
   for (int c = 0; c < kNumTileCfg; ++c) {
     if (width % kCfgBN[c] != 0) continue;
     const long long tiles = ((rows + kCfgBM[c] - 1) / kCfgBM[c]) * (width / kCfgBN[c]);
@@ -749,7 +814,7 @@ hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipSt
   if (a.M <= 0) return hipSuccess;
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
   if (cfg == kSkinnyCfg) {
-    if (a.N % KBN != 0 || a.K % KBK != 0 || a.n_out > 16) return hipErrorInvalidValue;
+    if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
     return epi_red ? launch_skinny<true>(a, s) : launch_skinny<false>(a, s);
   }
   if (cfg < 0 || cfg >= kNumTileCfg || a.N % kCfgBN[cfg] != 0 || a.K % 64 != 0 || a.K < 128 || a.n_out > 16) return hipErrorInvalidValue;

@@ -36,6 +36,8 @@ struct ikf_model {
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
   uint16_t* split_arena = nullptr;  // split-32 images of the hidden Linear weights
   std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
+  float* wfrag_arena = nullptr;          // fragment-major images of the hidden Linear weights (small-batch kernel)
+  std::vector<const float*> w_mid_frag;  // [subnet][layer], same flattening; null when the width does not fit
 
   // packed weights (one arena)
   float* arena = nullptr;
@@ -172,6 +174,7 @@ extern "C" void ikf_destroy(ikf_model* m) {
   free_exact(m);
   if (m->arena) (void)hipFree(m->arena);
   if (m->split_arena) (void)hipFree(m->split_arena);
+  if (m->wfrag_arena) (void)hipFree(m->wfrag_arena);
   if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
   if (m->d_Minv) (void)hipFree(m->d_Minv);
   if (m->d_blin) (void)hipFree(m->d_blin);
@@ -231,6 +234,28 @@ static ikf_status build_split_weights(ikf_model* m) {
       uint16_t* dst = m->split_arena + li * per;
       IKF_HIP(launch_split32_pack(m->subnets[si].w_mid[l], W, W, dst, nullptr));
       m->w_mid_split[(size_t)si * 3 + l] = dst;
+    }
+  IKF_HIP(hipDeviceSynchronize());
+  return IKF_OK;
+}
+
+// fragment-major images (k_wfrag_pack) of every hidden Linear weight for k_flow_gemm_skinny (rows <= 512): the second
+// copy costs width^2 * 4 B per layer (201 MB for the Panda model) of the 288 GB
+static ikf_status build_frag_weights(ikf_model* m) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes, W = d.width;
+  if (m->wfrag_arena) { (void)hipFree(m->wfrag_arena); m->wfrag_arena = nullptr; }
+  m->w_mid_frag.assign((size_t)2 * NB * 3, nullptr);
+  if (d.n_hidden < 2 || fused_pick_cfg(1, W) != fused_skinny_cfg()) return IKF_OK;
+  const size_t per = (size_t)W * W;
+  const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
+  IKF_HIP(hipMalloc(&m->wfrag_arena, sizeof(float) * per * n_layers));
+  size_t li = 0;
+  for (int si = 0; si < 2 * NB; ++si)
+    for (int l = 0; l < d.n_hidden - 1; ++l, ++li) {
+      float* dst = m->wfrag_arena + li * per;
+      IKF_HIP(launch_wfrag_pack(m->subnets[si].w_mid[l], W, W, dst, nullptr));
+      m->w_mid_frag[(size_t)si * 3 + l] = dst;
     }
   IKF_HIP(hipDeviceSynchronize());
   return IKF_OK;
@@ -372,7 +397,8 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
     ikf_status sst = build_split_weights(m);
     if (sst != IKF_OK) return sst;
   }
-  m->loaded = true;
+  ikf_status fst = build_frag_weights(m);
+  if (fst != IKF_OK) return fst;
   return IKF_OK;
 }
 
@@ -501,6 +527,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
         IKF_HIP(launch_split_gemm(last, (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width), sg, s));
       } else {
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
+        g.Wf = m->w_mid_frag[(size_t)(2 * b + which - 1) * 3 + l];
         IKF_HIP(launch_flow_gemm(last, cfg, g, s));
       }
       IKF_HIP(prof_mark(m, s));
@@ -738,6 +765,7 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
     // the contraction that reads its A operand from HBM and reduces the last Linear in its epilogue (h -> partials)
     g.M = (int)rows; g.N = m->dims.width; g.K = m->dims.width; g.slope = m->dims.slope;
     g.A = m->hA; g.W = w.w_mid[m->dims.n_hidden - 2]; g.bias = w.b_mid[m->dims.n_hidden - 2];
+    g.Wf = m->w_mid_frag.empty() ? nullptr : m->w_mid_frag[(size_t)(m->dims.n_hidden - 2)];
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = m->chunk_rows * IKF_PSTRIDE;
   }
   auto launch = [&]() -> hipError_t {

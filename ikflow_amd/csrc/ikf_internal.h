@@ -93,6 +93,7 @@ struct FusedGemmArgs {
   // contraction C = lrelu(A . W^T + bias), K = N = width
   const float* A;     // [rows_pad][K]
   const float* W;     // [N][K]
+  const float* Wf;    // fragment-major image of W for k_flow_gemm_skinny (launch_wfrag_pack), or null
   const float* bias;  // [N]
   float* C;           // [rows_pad][N]  (unused when the epilogue reduces to partials)
   int M, N, K;
@@ -146,6 +147,8 @@ struct SplitGemmArgs {
 hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s);
 int split_pick_cfg(long long rows, int width);
 void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // host-side packer (probe tool)
+int fused_skinny_cfg();
+hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream_t s);
 hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, hipStream_t s);
 const char* split_kernel_name();
 

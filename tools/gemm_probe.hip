@@ -141,6 +141,7 @@ int main(int argc, char** argv) {
   if (vsel >= 100) {  // the fused-pipeline contraction (k_flow_gemm<false>, tile config vsel-100): timing + in-kernel timeline
     ikf::FusedGemmArgs g{}; g.A = A; g.W = W; g.bias = b; g.C = C; g.M = M; g.N = N; g.K = K; g.slope = 0.01f;
     const int cfg = vsel - 100;
+    float* Wf; CK(hipMalloc(&Wf, (size_t)N * K * 4)); CK(ikf::launch_wfrag_pack(W, N, K, Wf, 0)); g.Wf = Wf;
     CK(hipMemset(C, 0, (size_t)Mp * N * 4));
     CK(ikf::launch_flow_gemm(false, cfg, g, 0)); CK(hipDeviceSynchronize());
     CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
