@@ -242,14 +242,21 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int row_t = t / KQ, kq_t = (t % KQ) * 4;
-  const float* a_src[A_F4];
+  // buffer loads: SGPR descriptor + loop-invariant 32-bit byte offset per thread + scalar k offset.  (A global_load
+  // with a 64-bit VGPR address costs its SIMD roughly three times the issue time and needs vector address arithmetic.)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, 0x7fffffff, 0x00020000);
+  unsigned a_off[A_F4], b_off[B_F4];
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     int gr = m0 + row_t + i * RS;
     gr = gr < M ? gr : M - 1;
-    a_src[i] = g.A + (size_t)gr * K + kq_t;
+    a_off[i] = ((unsigned)gr * (unsigned)K + kq_t) * 4u;
   }
-  const float* b_base = g.W + (size_t)(n0 + row_t) * K + kq_t;
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) b_off[i] = ((unsigned)(n0 + row_t + i * RS) * (unsigned)K + kq_t) * 4u;
+#define IKF_BLD(rs, voff, koff) \
+  __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane((koff) * 4), 0))
   const int lds_t = row_t * LDK + kq_t;
   const int fragA = (wm + (lane & 31)) * LDK + (lane >> 5) * 4;
   const int fragB = BM * LDK + (wn + (lane & 31)) * LDK + (lane >> 5) * 4;
@@ -260,9 +267,8 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 
 #define IKF_GLOAD(S, koff)                                                                                        \
   {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[S][i] = *reinterpret_cast<const floatx4*>(a_src[i] + (koff)); \
-    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
-        rb[S][i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (koff));                     \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[S][i] = IKF_BLD(rsA, a_off[i], koff);                      \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i) rb[S][i] = IKF_BLD(rsW, b_off[i], koff);                      \
   }
 #define IKF_LSTORE(S, stage)                                                                                      \
   {                                                                                                               \
@@ -360,9 +366,9 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
   {
     floatx4 ra0[A_F4], rb0[B_F4];
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) ra0[i] = *reinterpret_cast<const floatx4*>(a_src[i]);
+    for (int i = 0; i < A_F4; ++i) ra0[i] = IKF_BLD(rsA, a_off[i], 0);
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) rb0[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K);
+    for (int i = 0; i < B_F4; ++i) rb0[i] = IKF_BLD(rsW, b_off[i], 0);
     if (KT > 1) IKF_GLOAD(1, BK)       // tile 1 -> set 1 (stored by iteration 0)
     if (KT > 2) IKF_GLOAD(0, 2 * BK)   // tile 2 -> set 0 (stored by iteration 1)
     float* sp0 = smem + lds_t;
@@ -395,6 +401,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
   }
   IKF_TSTAMP(40)
 #undef IKF_GLOAD
+#undef IKF_BLD
 #undef IKF_LSTORE
 #undef IKF_FRAG
 #undef IKF_MFMA4
