@@ -244,7 +244,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if args.precision == "f32" else "f16x3 (error-compensated f16 MFMA, f32 accumulate)",
         "data": "synthetic (seeded random weights of the released architecture; poses = FK(uniform q); N(0,1) latents)",
         "config": {"workload": f"{args.model} generate_ik_solutions, B={B} poses per GPU per step, clamp_to_joint_limits",
                    "global_batch": world * B, "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: LDS-DMA destinations go through M0
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
 
   floatx16 am[MI][NI], ac[MI][NI];
@@ -351,22 +351,26 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
   // DMA sources: this wave fills chunks c = wave + 4q (q = 0..7) of every stage; chunk c < 16 is A lines 8c..8c+7, else W
   // lines 8(c-16)..; lane i of the instruction lands on line 8c + i/8, physical slot i%8 -> fetches logical slot
   // (i%8) ^ ((line >> 1) & 7) of that line
-  const float* Af = reinterpret_cast<const float*>(g.A);
-  const float* Wf = reinterpret_cast<const float*>(g.W);
-  const float* dsrc[8];
+  // (buffer form: SGPR descriptor + loop-invariant 32-bit byte offset + scalar k offset; no 64-bit vector addresses)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.A)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.W)), 0, 0x7fffffff, 0x00020000);
+  unsigned doff[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
     const int c = wave + 4 * q;
     const int line = (c & 15) * 8 + (lane >> 3);          // tile-local line within its operand
     const int ls = (lane & 7) ^ ((line >> 1) & 7);        // logical slot to fetch
-    if (c < 16) {
+    if (q < 4) {                                          // c < 16  <=>  q < 4 (wave < 4)
       int gr = m0 + line;
       gr = gr < M ? gr : M - 1;
-      dsrc[q] = Af + (size_t)gr * K + ls * 4;
+      doff[q] = ((unsigned)gr * (unsigned)K + ls * 4) * 4u;
     } else {
-      dsrc[q] = Wf + (size_t)(n0 + line) * K + ls * 4;
+      doff[q] = ((unsigned)(n0 + line) * (unsigned)K + ls * 4) * 4u;
     }
   }
+#define IKD_DMA1(q, kt_, st_)                                                                                      \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds((q) < 4 ? rsA : rsW, (lds_ptr_t)((st_) + (wave + 4 * (q)) * 256), 16, doff[q], \
+                                       __builtin_amdgcn_readfirstlane((kt_) * 128), 0, 0);
   // fragment reads: line r = w? + 32 i + (lane & 31), logical slot plane*4 + step*2 + (lane >> 5), physical = logical ^ swz
   const int swz = ((lane & 31) >> 1) & 7;
   const int fragA = (wm + (lane & 31)) * LINE;
@@ -377,8 +381,7 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
 #define IKD_DMA(kt_)                                                                                               \
   {                                                                                                               \
     float* st_ = smem + ((kt_) & 3) * STAGE;                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 8; ++q)                                                                 \
-        __builtin_amdgcn_global_load_lds(dsrc[q] + (size_t)(kt_) * 32, (lds_ptr_t)(st_ + (wave + 4 * q) * 256), 16, 0, 0); \
+    _Pragma("unroll") for (int q = 0; q < 8; ++q) IKD_DMA1(q, kt_, st_)                                           \
   }
 #define IKD_FRAG(AH, AL, BH, BL, kt_, s_)                                                                          \
   {                                                                                                               \
@@ -431,8 +434,7 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
       const int ktn = kt + 3 < KT ? kt + 3 : KT - 1;
       float* st_ = smem + ((kt + 3) & 3) * STAGE;
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        __builtin_amdgcn_global_load_lds(dsrc[q] + (size_t)ktn * 32, (lds_ptr_t)(st_ + (wave + 4 * q) * 256), 16, 0, 0);
+      for (int q = 0; q < 8; ++q) IKD_DMA1(q, ktn, st_)
     }
     IKD_FRAG(ah0, al0, bh0, bl0, kt + 1, 0)  // next tile's first step (harmless stale read after the last tile)
     IKD_MFMA3(ah1, al1, bh1, bl1)
@@ -448,6 +450,7 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
 #endif
   }
 #undef IKD_DMA
+#undef IKD_DMA1
 #undef IKD_FRAG
 #undef IKD_MFMA3
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the stage area is reused
