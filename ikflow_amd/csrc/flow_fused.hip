@@ -777,11 +777,20 @@ constexpr int kSkinnyCfg = 4;  // k_flow_gemm_skinny
 int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_pick_cfg(long long rows, int width) {
   if (rows <= 512 && width % KBN == 0 && width % (2 * KBK) == 0) return kSkinnyCfg;
-  for (int c = 0; c < kNumTileCfg; ++c) {
+  // Cost model fitted to the in-chain sweep (tools/cfg_sweep.py -> profiles/r01_cfg_sweep.jsonl; us per contraction at
+  // K = 1024, only the ratios matter): the 128x128 and 64x128 tiles run one workgroup per CU, so a launch costs whole
+  // rounds of 256 tiles (64.2 / 34 us); two 64x64 workgroups share a CU: 16.5 us per 256 tiles, 19.8 when alone.
+  // E.g. 3072 rows: 128x128 = 1 round = 64 us, 64x128 = 2 rounds = 68 us, 64x64 = 3 x 16.5 = 50 us.
+  int best = -1;
+  double best_t = 0.0;
+  for (int c = 0; c < 3; ++c) {
     if (width % kCfgBN[c] != 0) continue;
     const long long tiles = ((rows + kCfgBM[c] - 1) / kCfgBM[c]) * (width / kCfgBN[c]);
-    if (tiles >= 256) return c;
+    const double rounds = (double)((tiles + 255) / 256);
+    const double t = c == 0 ? 64.2 * rounds : c == 1 ? 34.0 * rounds : (tiles <= 256 ? 19.8 : 16.5 * rounds);
+    if (best < 0 || t < best_t - 1e-9) { best = c; best_t = t; }
   }
+  if (best >= 0) return best;
   for (int c = kNumTileCfg - 1; c >= 0; --c)
     if (width % kCfgBN[c] == 0) return c;
   return -1;

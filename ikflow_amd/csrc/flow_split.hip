@@ -554,12 +554,13 @@ static hipError_t launch_sg_dma(const SplitGemmArgs& a, hipStream_t s) {
 const char* split_kernel_name() { return "k_split_gemm_dma"; }
 
 int split_pick_cfg(long long rows, int width) {
-  for (int c = 0; c < kNumSplitCfg; ++c) {
-    if (width % kSplitBN[c] != 0) continue;
-    const long long tiles = ((rows + kSplitBM[c] - 1) / kSplitBM[c]) * (width / kSplitBN[c]);
-    if (tiles >= 256) return c;
-  }
-  for (int c = kNumSplitCfg - 1; c >= 0; --c)
+  // from the in-chain sweep (tools/cfg_sweep.py -> profiles/r01_cfg_sweep.jsonl): 32x64 up to 512 rows, 64x64 up to
+  // 1024, 64x128 up to 2048, and above that the LDS-DMA 128x128 kernel even with idle CUs (2560 rows: 1.31 ms against
+  // 1.72 ms for two rounds of 64x128)
+  const int want = rows > 2048 ? 0 : rows > 1024 ? 1 : rows > 512 ? 2 : 3;
+  for (int c = want; c < kNumSplitCfg; ++c)
+    if (width % kSplitBN[c] == 0) return c;
+  for (int c = want - 1; c >= 0; --c)
     if (width % kSplitBN[c] == 0) return c;
   return -1;
 }

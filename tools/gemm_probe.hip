@@ -101,8 +101,8 @@ int main(int argc, char** argv) {
       printf("block %3d: pending %llu  publish+U %llu  first-Linear+store %llu  total %llu cycles\n", bI, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[3] - r[0]); }
     return 0;
   }
-  const int scfg = (vsel == 210) ? 10 : 11;
-  if (vsel == 200 || vsel == 210) {  // the f16-split contraction (k_split_gemm<false>): correctness vs the fp32 reference, timing, timeline
+  const int scfg = (vsel == 210) ? 10 : (vsel == 200 || vsel == 211) ? 11 : vsel - 200;  // 201..203: smaller split tiles
+  if (vsel >= 200 && vsel < 300) {  // the f16-split contraction (k_split_gemm<false>): correctness vs the fp32 reference, timing, timeline
     std::vector<uint16_t> sA((size_t)Mp * K * 2), sW((size_t)N * K * 2);
     ikf::split32_pack_host(hA.data(), Mp, K, sA.data()); ikf::split32_pack_host(hW.data(), N, K, sW.data());
     void *dsA, *dsW, *dsC; CK(hipMalloc(&dsA, sA.size() * 2)); CK(hipMalloc(&dsW, sW.size() * 2)); CK(hipMalloc(&dsC, (size_t)Mp * N * 4));
