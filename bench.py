@@ -234,7 +234,7 @@ def main():
         extra.update(run_extras(solver, eng, robot, layout, dev))
 
     out = {
-        "metric": "IK solutions/sec (approx), Panda 12-node flow, batch 4096 per GPU",
+        "metric": f"IK solutions/sec (approx), {'Panda 12-node' if 'panda' in args.model else args.model} flow, batch {B} per GPU",
         "value": value,
         "unit": "IK solutions/s",
         "n_gpus": world,
