@@ -673,6 +673,31 @@ extern "C" ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, 
   return IKF_OK;
 }
 
+// model-free evaluation helpers (current device; evaluation_utils.py:37-51, :100-112)
+extern "C" ikf_status ikf_pose_distance(const float* d_poses_a, const float* d_poses_b, int64_t n, float acos_epsilon,
+                                        float* d_pos_err, float* d_rot_err, void* stream) {
+  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_pose_distance: n must be >= 0");
+  if (n == 0) return IKF_OK;
+  if (!d_poses_a || !d_poses_b || !d_pos_err || !d_rot_err)
+    return fail(IKF_ERR_NULL_POINTER, "ikf_pose_distance: null device pointer");
+  IKF_HIP(launch_pose_distance(d_poses_a, d_poses_b, n, acos_epsilon, d_pos_err, d_rot_err,
+                               static_cast<hipStream_t>(stream)));
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_limits_exceeded(const float* d_q, int64_t n, int n_cols, const float* h_lower,
+                                          const float* h_upper, uint8_t* d_exceeded_out, void* stream) {
+  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_limits_exceeded: n must be >= 0");
+  if (n_cols < 1 || n_cols > IKF_MAX_LIMIT_COLS)
+    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_limits_exceeded: n_cols must be in [1, 32]");
+  if (n == 0) return IKF_OK;
+  if (!d_q || !h_lower || !h_upper || !d_exceeded_out)
+    return fail(IKF_ERR_NULL_POINTER, "ikf_limits_exceeded: null pointer");
+  IKF_HIP(launch_limits_exceeded_table(h_lower, h_upper, n_cols, d_q, n, d_exceeded_out,
+                                       static_cast<hipStream_t>(stream)));
+  return IKF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // exact IK
 // ---------------------------------------------------------------------------------------------------------------

@@ -170,6 +170,11 @@ hipError_t launch_clamp(const Chain* d_chain, int ndof, const float* q, long lon
 hipError_t launch_limits_exceeded(const Chain* d_chain, int ndof, const float* q, long long n, uint8_t* out,
                                   hipStream_t s);
 // exact-IK round kernels
+constexpr int IKF_MAX_LIMIT_COLS = 32;
+hipError_t launch_pose_distance(const float* a, const float* b, long long n, float acos_eps, float* pe, float* re,
+                                hipStream_t s);
+hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int ncols, const float* q, long long n,
+                                        uint8_t* out, hipStream_t s);
 hipError_t launch_exact_lm_iter(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx,
                                 int n_active, int repeat, float* q, const uint8_t* solved, uint8_t* row_valid,
                                 float pos_thr, float rot_thr, hipStream_t s);

@@ -328,6 +328,45 @@ __global__ __launch_bounds__(256) void k_limits_exceeded(const Chain* __restrict
   out[row] = ex ? 1 : 0;
 }
 
+// evaluation_utils.pose_errors (ikflow/evaluation_utils.py:37-51): L2 of the positions, geodesic of the quaternions.
+// acos_eps < 0 selects the jrl default clamp (1e-7, as in k_pose_error).
+__global__ __launch_bounds__(256) void k_pose_distance(const float* __restrict__ a, const float* __restrict__ b,
+                                                       long long n, float acos_eps, float* __restrict__ pos_err,
+                                                       float* __restrict__ rot_err) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const float* pa = a + (size_t)row * 7;
+  const float* pb = b + (size_t)row * 7;
+  const float dx = pa[0] - pb[0], dy = pa[1] - pb[1], dz = pa[2] - pb[2];
+  pos_err[row] = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (acos_eps < 0.f) {
+    rot_err[row] = geodesic_f32(pa + 3, pb + 3);
+  } else {
+    float dot = pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5] + pa[6] * pb[6];
+    dot = fminf(fmaxf(dot, -1.0f + acos_eps), 1.0f - acos_eps);
+    const float PI_F = 3.14159265358979323846f, TWO_PI_F = 6.28318530717958647692f;
+    float m = fmodf(2.0f * acosf(dot) + PI_F, TWO_PI_F);
+    if (m < 0.f) m += TWO_PI_F;
+    rot_err[row] = fabsf(m - PI_F);
+  }
+}
+
+// evaluation_utils.calculate_joint_limits_exceeded for an arbitrary limits table (evaluation_utils.py:100-112)
+struct LimitsTable {
+  float lo[IKF_MAX_LIMIT_COLS], hi[IKF_MAX_LIMIT_COLS];
+};
+__global__ __launch_bounds__(256) void k_limits_exceeded_table(LimitsTable t, int ncols, const float* __restrict__ q,
+                                                               long long n, uint8_t* __restrict__ out) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  bool ex = false;
+  for (int j = 0; j < ncols; ++j) {
+    const float v = q[(size_t)row * ncols + j];
+    ex = ex || (v > t.hi[j]) || (v < t.lo[j]);  // strict
+  }
+  out[row] = ex ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // exact-IK round kernels.  Row layout of q is the reference's tile-major one: row = r * n_active + j  <->  repeat r of
 // active pose j (cond.repeat((R,1)), ikflow_solver.py:185).  Poses solved in an earlier iteration are masked instead
@@ -450,6 +489,21 @@ hipError_t launch_limits_exceeded(const Chain* ch, int ndof, const float* q, lon
                                   hipStream_t s) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_limits_exceeded, dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, ndof, q, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_pose_distance(const float* a, const float* b, long long n, float acos_eps, float* pe, float* re,
+                                hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pose_distance, dim3(blocks_for(n, 256)), dim3(256), 0, s, a, b, n, acos_eps, pe, re);
+  return hipGetLastError();
+}
+hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int ncols, const float* q, long long n,
+                                        uint8_t* out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (ncols < 1 || ncols > IKF_MAX_LIMIT_COLS) return hipErrorInvalidValue;
+  LimitsTable t{};
+  for (int j = 0; j < ncols; ++j) { t.lo[j] = lo[j]; t.hi[j] = hi[j]; }
+  hipLaunchKernelGGL(k_limits_exceeded_table, dim3(blocks_for(n, 256)), dim3(256), 0, s, t, ncols, q, n, out);
   return hipGetLastError();
 }
 hipError_t launch_exact_lm_iter(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active,

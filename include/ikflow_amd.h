@@ -126,6 +126,17 @@ ikf_status ikf_clamp_to_joint_limits(ikf_model* m, const float* d_q, int64_t n, 
 ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, int64_t n, uint8_t* d_exceeded_out,
                                      void* stream);
 
+/* Model-free helpers of the evaluation path, on the current device.
+ * evaluation_utils.pose_errors (ikflow/evaluation_utils.py:37-51): [n x 7] vs [n x 7] -> L2 position error and
+ * quaternion geodesic; acos_epsilon < 0 selects the jrl default (1e-7). */
+ikf_status ikf_pose_distance(const float* d_poses_a, const float* d_poses_b, int64_t n, float acos_epsilon,
+                             float* d_pos_err, float* d_rot_err, void* stream);
+/* evaluation_utils.calculate_joint_limits_exceeded for any limits table (ikflow/evaluation_utils.py:100-112; the
+ * reference's own test uses a 3-column table, tests/evaluation_utils_test.py:36-57): d_q [n x n_cols] on the device,
+ * h_lower / h_upper [n_cols] on the host, n_cols <= 32; strict inequalities. */
+ikf_status ikf_limits_exceeded(const float* d_q, int64_t n, int n_cols, const float* h_lower, const float* h_upper,
+                               uint8_t* d_exceeded_out, void* stream);
+
 /* -- exact IK: replaces generate_exact_ik_solutions + _generate_exact_ik_solutions (:119-247, :345-411) ----- */
 /* Callback that supplies the latent for retry round `round`: must fill (or return a pointer to) a device buffer of
  * [rows x D] fp32 laid out tile-major exactly as the reference draws it (`draw_latent(..., (n_tiled, D))`, :187).

@@ -273,6 +273,61 @@ def test_pose_error_jacobian_clamp_limits():
     assert torch.equal(ex, ko.calculate_joint_limits_exceeded(wild, robot.actuated_joints_limits))
 
 
+def test_evaluation_utils_reference_known_answers_and_oracle():
+    """ikflow/evaluation_utils.py mirror: the reference's own known answers (tests/evaluation_utils_test.py:14-57) and the
+    oracle on random poses, torch and numpy inputs."""
+    from ikflow_amd import evaluation_utils as eu
+    from ikflow_amd.robots import Panda
+
+    robot = Panda()
+    # tests/evaluation_utils_test.py:18-32 - one target pose, the zero configuration
+    target_pose = torch.tensor([1.0, 1.0, 1.0, 1.0, 0.0, 0.0, 0.0], dtype=torch.float32)
+    solutions = torch.zeros((1, 7), dtype=torch.float32)
+    l2, ang = eu.solution_pose_errors(robot, solutions, target_pose)
+    assert l2.device.type == "cpu" and l2.shape == (1,)
+    assert abs(l2[0].item() - 1.355440887681938) < 1e-6
+    assert abs(ang[0].item() - 3.1415927) < 5e-4
+    # tests/evaluation_utils_test.py:36-57 - 3-column limits table, strict inequalities
+    configs = torch.tensor([[0, 0, 0], [0, 0, 0], [-2, 0, 0], [0, -1.999, 0], [0, 2.0001, 0]])
+    returned = eu.calculate_joint_limits_exceeded(configs, [(-1, 1), (-2, 2), (-3, 3)])
+    assert returned.dtype == torch.bool and returned.shape == (5,)
+    assert torch.equal(returned, torch.tensor([False, False, True, False, True]))
+
+    # pose_errors / pose_errors_cm_deg against the oracle, torch (device) and numpy inputs
+    n = 777
+    g = torch.Generator().manual_seed(3)
+    p1 = torch.randn(n, 7, generator=g)
+    p2 = torch.randn(n, 7, generator=g)
+    p1[:, 3:] /= p1[:, 3:].norm(dim=1, keepdim=True)
+    p2[:, 3:] /= p2[:, 3:].norm(dim=1, keepdim=True)
+    p2[:5] = p1[:5]  # identical poses: the acos clamp decides the result
+    l2_ref = torch.norm(p1[:, :3] - p2[:, :3], dim=1)
+    ang_ref = ko.geodesic_distance_between_quaternions(p1[:, 3:], p2[:, 3:])
+    l2, ang = eu.pose_errors(p1.to(DEV), p2.to(DEV))
+    assert l2.is_cuda and (l2.cpu() - l2_ref).abs().max().item() <= 2e-6
+    assert (ang.cpu() - ang_ref).abs().max().item() <= 2e-5
+    l2n, angn = eu.pose_errors(p1.numpy(), p2.numpy())
+    assert isinstance(l2n, np.ndarray) and np.array_equal(l2n, l2.cpu().numpy()) and np.array_equal(angn, ang.cpu().numpy())
+    cm, deg = eu.pose_errors_cm_deg(p1, p2)
+    assert torch.allclose(cm, 100 * l2.cpu()) and torch.allclose(deg, torch.rad2deg(ang.cpu()))
+    ang_eps = eu.pose_errors(p1[:5].to(DEV), p2[:5].to(DEV), acos_epsilon=1e-3)[1].cpu()
+    assert (ang_eps - ko.geodesic_distance_between_quaternions(p1[:5, 3:], p2[:5, 3:], acos_epsilon=1e-3)).abs().max().item() <= 2e-5
+    with pytest.raises(AssertionError):
+        eu.pose_errors(p1, p2[:10])
+
+    # evaluate_solutions: batch and single-pose forms
+    q, poses = reachable_poses(robot, 300, 4)
+    wild = (q + 0.5 * torch.randn(300, 7, generator=g)).float()
+    l2e, ange, lim, coll = eu.evaluate_solutions(robot, poses, wild)
+    pe_ref, re_ref = ko.calculate_pose_error(robot, wild, poses)
+    assert (l2e - pe_ref).abs().max().item() <= 2e-6 and (ange - re_ref).abs().max().item() <= 2e-5
+    assert torch.equal(lim, ko.calculate_joint_limits_exceeded(wild, robot.actuated_joints_limits)) and coll is None
+    l2s, _, _, _ = eu.evaluate_solutions(robot, poses[0], wild)
+    assert (l2s - ko.calculate_pose_error(robot, wild, poses[0].repeat(300, 1))[0]).abs().max().item() <= 2e-6
+    with pytest.raises(NotImplementedError):
+        eu.calculate_self_collisions(robot, wild)
+
+
 @pytest.mark.parametrize("which", ["panda", "fetch_arm"])
 def test_lm_step_matches_fp64_twin(which):
     from ikflow_amd.robots import get_robot

@@ -190,3 +190,20 @@ def test_fold_chain_matches_joint_by_joint_fk():
 def test_config_and_device_rule():
     assert config.DEFAULT_TORCH_DTYPE == torch.float32
     assert config.DEVICE == ("cuda:0" if torch.cuda.is_available() else "cpu") or config.DEVICE.startswith("cuda:")
+
+
+def test_evaluation_utils_host_side():
+    """target-pose tiling rule of evaluation_utils.py:22-34 and the no-CPU-path contract of the mirror module."""
+    from ikflow_amd import evaluation_utils as eu
+    from ikflow_amd.engine import EngineError
+
+    one = torch.arange(7, dtype=torch.float32)
+    assert eu._get_target_pose_batch(one, 4).shape == (4, 7)
+    assert eu._get_target_pose_batch(one.numpy(), 3).shape == (3, 7)
+    batch = torch.zeros(5, 7)
+    assert eu._get_target_pose_batch(batch, 5) is batch
+    if not torch.cuda.is_available():
+        with pytest.raises(EngineError):
+            eu.pose_errors(batch, batch)
+        with pytest.raises(EngineError):
+            eu.calculate_joint_limits_exceeded(torch.zeros(2, 3), [(-1, 1)] * 3)
