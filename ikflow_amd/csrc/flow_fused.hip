@@ -523,17 +523,23 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
 // registers each).  (The slice split changes the summation order with respect to the large tiles: results agree to
 // rounding, not bit for bit, across the 512-row boundary.)
 // ---------------------------------------------------------------------------------------------------------------
+// NH = column halves per workgroup: 2 -> 32x64 tiles, 16 waves (257..512 rows: <= 256 tiles); 1 -> 32x32 tiles, 8 waves
+// (<= 256 rows: still <= 256 tiles, and half the matrix-pipe time per stage - the per-launch latency drops by a third).
 constexpr int KBM = 32, KBN = 64, KBK = 128;
-constexpr int KKS = 8;               // k-slices per tile (waves = 2 column halves x KKS)
-constexpr int KNT = 2 * KKS * 64;    // 1024 threads: four waves per SIMD
+constexpr int KKS = 8;               // k-slices per tile (waves = NH column halves x KKS)
 constexpr int KKW = KBK / KKS;       // k per wave per tile (16)
 constexpr int KKG = KKW / 8;         // MFMA groups (8 k = 4 MFMAs) per wave per tile (2)
 // LDS: two A stages in the loop; afterwards the KKS partial blocks + the epilogue's T / w_last tiles
-constexpr size_t kSkinnyLds = sizeof(float) * ((size_t)KKS * 2 * 16 * 64 + (size_t)(KBM + 32) * (KBN + 4));
+template <int NH>
+constexpr size_t skinny_lds() {
+  return sizeof(float) * ((size_t)KKS * NH * 16 * 64 + (size_t)(KBM + 32) * (NH * 32 + 4)) > sizeof(float) * 2 * KBM * (KBK + 4)
+             ? sizeof(float) * ((size_t)KKS * NH * 16 * 64 + (size_t)(KBM + 32) * (NH * 32 + 4))
+             : sizeof(float) * 2 * KBM * (KBK + 4);
+}
 
-template <bool EPI_RED>
-__global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
-  constexpr int BM = KBM, BN = KBN, BK = KBK, NT = KNT, KS = KKS;
+template <bool EPI_RED, int NH>
+__global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArgs g) {
+  constexpr int BM = KBM, BN = NH * 32, BK = KBK, NT = NH * KKS * 64, KS = KKS;
   constexpr int LDK = BK + 4;
   constexpr int KQ4 = BK / 4;           // float4 per tile row
   constexpr int NFA = BM * KQ4 / NT;    // float4 of the A tile per thread per stage
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
   constexpr int LDT = BN + 4;
   static_assert(BM * KQ4 % NT == 0 && NFA >= 1, "tile/threads mismatch");
   static_assert(KKG == 2, "the iteration below is written for two MFMA groups per wave per tile");
-  static_assert(kSkinnyLds >= sizeof(float) * 2 * STAGE, "the two A stages must fit");
+  static_assert(skinny_lds<NH>() >= sizeof(float) * 2 * STAGE, "the two A stages must fit");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BM][LDK] / reduction scratch
 
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // wave id as a scalar
-  const int nh = wave & 1, kq = wave >> 1;
+  const int nh = wave % NH, kq = wave / NH;
 
   floatx16 acc;
 #pragma unroll
@@ -573,13 +579,13 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
     aoff[i] = ((unsigned)gr * (unsigned)K + c4 * 4) * 4u;
     ldst[i] = row * LDK + c4 * 4;
   }
-  constexpr int WTILE = 2 * KS * KKG * 256;  // floats per (column tile, k tile) = 64 x 128
+  constexpr int WTILE = KS * KKG * 256;  // floats per (32-column tile, k tile) = 32 x 128
   const int KT = K / BK;
   // buffer loads: (SGPR descriptor) + (loop-invariant 32-bit VGPR offset) + (scalar tile offset)
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
-  const unsigned wtile0 = (unsigned)tn * KT;                                     // (column tile, k tile 0)
-  const unsigned woff = (unsigned)((kq * 2 + nh) * (KKG * 256) * 4) + lane * 16u;  // wave's slice + lane, bytes
+  const unsigned wtile0 = (unsigned)(tn * NH + nh) * KT;                   // (this wave's 32-column tile, k tile 0)
+  const unsigned woff = (unsigned)(kq * (KKG * 256) * 4) + lane * 16u;     // wave's k-slice + lane, bytes
   const int fragA = (lane & 31) * LDK + kq * KKW + (lane >> 5) * 4;
 #define IKK_LDA(i, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[i], __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
 #define IKK_LDW(kk, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff + (kk) * 1024, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
@@ -664,9 +670,9 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
 
   // ---- sum the k-slice partial blocks in fixed order kq = 0, 1, ..: every wave parks its block in LDS, then wave
   // (kq, nh) finishes accumulator registers 2*kq and 2*kq+1 (two output rows per lane half) of column half nh
-  float* red = smem;  // [KS][2][16][64]
+  float* red = smem;  // [KS][NH][16][64]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[((kq * 2 + nh) * 16 + r) * 64 + lane] = acc[r];
+  for (int r = 0; r < 16; ++r) red[((kq * NH + nh) * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   float fin[2];
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
     const int r = 2 * kq + j;
     float v = 0.f;
 #pragma unroll
-    for (int q = 0; q < KS; ++q) v += red[((q * 2 + nh) * 16 + r) * 64 + lane];
+    for (int q = 0; q < KS; ++q) v += red[((q * NH + nh) * 16 + r) * 64 + lane];
     v += g.bias[n0 + nh * 32 + col_l];
     fin[j] = v > 0.f ? v : v * g.slope;
   }
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
       g.C[(size_t)row * N + n0 + nh * 32 + col_l] = fin[j];  // row-padded buffer: unpredicated
     }
   } else {
-    float* T = smem + KS * 2 * 16 * 64;  // behind red[] (other waves may still be summing)
+    float* T = smem + KS * NH * 16 * 64;  // behind red[] (other waves may still be summing)
     float* Wl = T + BM * LDT;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -702,14 +708,14 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
       *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
     }
     __syncthreads();
-    if (wave == 0) {  // one 64-column slot per tile, same MFMA order as every other configuration
+    if (wave == 0) {  // one slot per tile (64 columns: same MFMA order as the large tiles; 32 columns: half slots)
       floatx16 pacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
       const float* pa = Wl + (lane & 31) * LDT + (lane >> 5) * 4;
       const float* pb = T + (lane & 31) * LDT + (lane >> 5) * 4;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
+      for (int ks = 0; ks < BN / 8; ++ks) {
         const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
         const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
@@ -717,7 +723,7 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
       }
-      float* pout = g.P_out + (size_t)(n0 / 64) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
+      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int o = (r & 3) + 8 * (r >> 2) + row_h;
@@ -729,8 +735,8 @@ __global__ __launch_bounds__(KNT) void k_flow_gemm_skinny(FusedGemmArgs g) {
 }
 
 // fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
-//   ((((tn*KT + kt)*KKS + kq)*2 + nh)*KKG + kk)*64 + lane
-//        <-  W[tn*64 + nh*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
+//   (((tn32*KT + kt)*KKS + kq)*KKG + kk)*64 + lane  <-  W[tn32*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
+// (per 32-column tile and k tile: 8 k-slices x 2 MFMA groups x 64 lanes; a wave's fetch for one stage is 2 KB contiguous)
 __global__ __launch_bounds__(256) void k_wfrag_pack(const float* __restrict__ W, float* __restrict__ out, int N, int K) {
   const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= (size_t)N * K / 4) return;
@@ -738,11 +744,10 @@ __global__ __launch_bounds__(256) void k_wfrag_pack(const float* __restrict__ W,
   const int lane = (int)(f & 63);
   size_t r = f >> 6;
   const int kk = (int)(r % KKG); r /= KKG;
-  const int nh = (int)(r & 1); r >>= 1;
   const int kq = (int)(r % KKS); r /= KKS;
   const int kt = (int)(r % KT);
-  const int tn = (int)(r / KT);
-  const size_t row = (size_t)tn * KBN + nh * 32 + (lane & 31);
+  const int tn32 = (int)(r / KT);
+  const size_t row = (size_t)tn32 * 32 + (lane & 31);
   const int k = kt * KBK + kq * KKW + kk * 8 + (lane >> 5) * 4;
   reinterpret_cast<floatx4*>(out)[f] = *reinterpret_cast<const floatx4*>(W + row * K + k);
 }
@@ -753,10 +758,10 @@ hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream
   return hipGetLastError();
 }
 
-template <bool EPI_RED>
+template <bool EPI_RED, int NH>
 static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = kSkinnyLds;
-  auto kern = k_flow_gemm_skinny<EPI_RED>;
+  constexpr size_t smem = skinny_lds<NH>();
+  auto kern = k_flow_gemm_skinny<EPI_RED, NH>;
   // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
   static bool attr_set[64] = {};
   int dev_ = 0;
@@ -767,16 +772,18 @@ static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_set[dev_] = true;
   }
-  const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / KBN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KNT), smem, s, a);
+  const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kSkinnyCfg = 4;  // k_flow_gemm_skinny
+constexpr int kSkinnyCfg = 4;    // k_flow_gemm_skinny<.., 2>: 32x64 tiles
+constexpr int kSkinny32Cfg = 6;  // k_flow_gemm_skinny<.., 1>: 32x32 tiles (5 is the 4-wave probe of the large tile)
 int fused_skinny_cfg() { return kSkinnyCfg; }
+int fused_skinny32_cfg() { return kSkinny32Cfg; }
 int fused_pick_cfg(long long rows, int width) {
-  if (rows <= 512 && width % KBN == 0 && width % (2 * KBK) == 0) return kSkinnyCfg;
+  if (rows <= 512 && width % KBN == 0 && width % (2 * KBK) == 0) return rows <= 256 ? kSkinny32Cfg : kSkinnyCfg;
   // Cost model fitted to the in-chain sweep (tools/cfg_sweep.py -> profiles/r01_cfg_sweep.jsonl; us per contraction at
   // K = 1024, only the ratios matter): the 128x128 and 64x128 tiles run one workgroup per CU, so a launch costs whole
   // rounds of 256 tiles (64.2 / 34 us); two 64x64 workgroups share a CU: 16.5 us per 256 tiles, 19.8 when alone.
@@ -795,13 +802,9 @@ int fused_pick_cfg(long long rows, int width) {
     if (width % kCfgBN[c] == 0) return c;
   return -1;
 }
-int fused_slots(int cfg, int width) { (void)cfg; return width / 64; }
-int fused_max_slots(int width) {
-  int m = 0;
-  for (int c = 0; c < kNumTileCfg; ++c)
-    if (width % kCfgBN[c] == 0 && fused_slots(c, width) > m) m = fused_slots(c, width);
-  return m;
-}
+// partial-sum slots of the last Linear: one per 64 columns, except the 32-column small-batch tiles (half slots)
+int fused_slots(int cfg, int width) { return cfg == kSkinny32Cfg ? width / 32 : width / 64; }
+int fused_max_slots(int width) { return width / 32; }
 const char* fused_kernel_name() { return "k_flow_gemm"; }
 
 template <bool EPI_RED, int CFG>
@@ -829,9 +832,10 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
-  if (cfg == kSkinnyCfg) {
+  if (cfg == kSkinnyCfg || cfg == kSkinny32Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
-    return epi_red ? launch_skinny<true>(a, s) : launch_skinny<false>(a, s);
+    if (cfg == kSkinnyCfg) return epi_red ? launch_skinny<true, 2>(a, s) : launch_skinny<false, 2>(a, s);
+    return epi_red ? launch_skinny<true, 1>(a, s) : launch_skinny<false, 1>(a, s);
   }
   if (cfg < 0 || cfg >= kNumTileCfg || a.N % kCfgBN[cfg] != 0 || a.K % 64 != 0 || a.K < 128 || a.n_out > 16) return hipErrorInvalidValue;
   switch (cfg) {

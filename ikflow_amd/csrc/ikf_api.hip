@@ -246,7 +246,7 @@ static ikf_status build_frag_weights(ikf_model* m) {
   const int NB = m->desc.nb_nodes, W = d.width;
   if (m->wfrag_arena) { (void)hipFree(m->wfrag_arena); m->wfrag_arena = nullptr; }
   m->w_mid_frag.assign((size_t)2 * NB * 3, nullptr);
-  if (d.n_hidden < 2 || fused_pick_cfg(1, W) != fused_skinny_cfg()) return IKF_OK;
+  if (d.n_hidden < 2 || fused_pick_cfg(512, W) != fused_skinny_cfg()) return IKF_OK;
   const size_t per = (size_t)W * W;
   const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
   IKF_HIP(hipMalloc(&m->wfrag_arena, sizeof(float) * per * n_layers));
@@ -444,7 +444,7 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
 
 extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
-  if (variant >= 100 && variant <= 105) {  // fused pipeline; 100 = tile by batch size, 101..105 = tile config 0..4
+  if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
     m->gemm_variant = 100;
     m->tile_cfg = variant - 101;
     return IKF_OK;
@@ -492,7 +492,11 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
   const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width);
-  const int slots = fused_slots(cfg, d.width);
+  // f16x3 is a throughput mode: up to 256 rows the exact-f32 32x32 small-batch kernel is the faster one (0.55-0.62 ms per
+  // call against 0.64-0.69, tools/cfg_sweep.py) and is used instead.  The f16-split kernels always reduce the last Linear
+  // in 64-column slots.
+  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && cfg == fused_skinny32_cfg());
+  const int slots = split ? d.width / 64 : fused_slots(cfg, d.width);
   PendingCoupling pend{};
   pend.P = nullptr;
   const float* x_src = d_latent + (size_t)r0 * d.D;
@@ -507,7 +511,6 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     e.x_off = (which == 1) ? 0 : d.L1; e.n_x = w.n_x;
     e.ps = ps; e.row0 = r0;
     e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
-    const bool split = (m->precision == 1) && m->split_arena != nullptr;
     e.width = d.width; e.slope = d.slope; e.h_out = m->hA; e.split_out = split ? 1 : 0;
     IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     FusedGemmArgs g{};

@@ -148,6 +148,7 @@ hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipS
 int split_pick_cfg(long long rows, int width);
 void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // host-side packer (probe tool)
 int fused_skinny_cfg();
+int fused_skinny32_cfg();
 hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream_t s);
 hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, hipStream_t s);
 const char* split_kernel_name();
