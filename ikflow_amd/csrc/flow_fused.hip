@@ -111,10 +111,17 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   const int M = e.M, D = e.D;
   // this thread's slice of the first Linear (first column group) is fetched up front: its L2 latency hides behind the
   // pending-coupling phase below
+  // Column split for small batches (gridDim.y workgroups share a row group, each redoing the cheap pending phase): the
+  // workgroup owns n4_per float4 column groups; when that is fewer than the 256 threads, the threads also split the rows
+  // (CPW columns x NT/CPW row groups of RPT rows).
   const int n4 = e.width >> 2;
+  const int n4_per = n4 / (int)gridDim.y, c4_base = (int)blockIdx.y * n4_per;
+  const int CPW = n4_per < NT ? n4_per : NT;
+  const int RPT = ER / (NT / CPW);
+  const int tc = t % CPW, r_first = (t / CPW) * RPT;
   floatx4 w0[IN], b0;
   {
-    const int c4 = t < n4 ? t : 0;
+    const int c4 = c4_base + tc;
 #pragma unroll
     for (int k = 0; k < IN; ++k) w0[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
     b0 = reinterpret_cast<const floatx4*>(e.b1)[c4];
@@ -136,14 +143,15 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, cat, t);
   IKF_TSTAMP(1)
   // publish the new state and assemble u = [x_part, pose, 0-pad]
-  if (uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
+  if (blockIdx.y == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
   U[ur * ROWBUF + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;
   __syncthreads();
   IKF_TSTAMP(2)
-  for (int c4 = t; c4 < n4; c4 += NT) {
+  for (int cc = tc; cc < n4_per; cc += CPW) {
+    const int c4 = c4_base + cc;
     floatx4 w[IN];
     floatx4 b;
-    if (c4 == t) {
+    if (cc == tc) {
 #pragma unroll
       for (int k = 0; k < IN; ++k) w[k] = w0[k];
       b = b0;
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     }
     if (e.ps.softflow != 0.0f) b += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft)[c4];
 #pragma unroll 4
-    for (int r = 0; r < ER; ++r) {
+    for (int r = r_first; r < r_first + RPT; ++r) {
       // the row's 16 inputs as four LDS broadcast reads (same address in every lane)
       float u[ROWBUF];
 #pragma unroll
@@ -850,8 +858,14 @@ hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s) {
   if (e.M <= 0) return hipSuccess;
   if (e.D > ROWBUF || e.pend.n_out > ROWBUF || e.width % 4 != 0) return hipErrorInvalidValue;
   const unsigned grid = (unsigned)((e.M + ER - 1) / ER);
+  // up to 1024 rows (<= 64 row groups) four workgroups share a row group's columns: the launch is a latency chain
+  // there and the first Linear of 16 rows x `width` is its longest link
+  const int n4 = e.width / 4;
+  unsigned cs = 1;
+  if (e.M <= 1024 && n4 % 4 == 0 && n4 / 4 >= 64) cs = 4;
+  else if (e.M <= 2048 && n4 % 2 == 0 && n4 / 2 >= 64) cs = 2;
 #define IKF_ENTRY_CASE(IN) \
-  case IN: hipLaunchKernelGGL((k_subnet_entry<IN>), dim3(grid), dim3(256), 0, s, e); break;
+  case IN: hipLaunchKernelGGL((k_subnet_entry<IN>), dim3(grid, cs), dim3(256), 0, s, e); break;
   switch (n_in) {
     IKF_ENTRY_CASE(8) IKF_ENTRY_CASE(9) IKF_ENTRY_CASE(10) IKF_ENTRY_CASE(11)
     IKF_ENTRY_CASE(12) IKF_ENTRY_CASE(13) IKF_ENTRY_CASE(14) IKF_ENTRY_CASE(15)
