@@ -83,16 +83,20 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
       for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac[i][j][r] = 0.f; }
 
   const int row_t = t / KQ, kq_t = (t % KQ) * 4;  // dword offset of this thread's 16-B slot in a line
-  const float* Af = reinterpret_cast<const float*>(g.A);
-  const float* Wf = reinterpret_cast<const float*>(g.W);
-  const float* a_src[A_F4];
+  // buffer loads (SGPR descriptor + loop-invariant 32-bit byte offset + scalar k offset), as in k_flow_gemm
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.A)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.W)), 0, 0x7fffffff, 0x00020000);
+  unsigned a_off[A_F4], b_off[B_F4];  // a split-32 row is K dwords long; K tile kt starts at dword 32*kt
 #pragma unroll
   for (int i = 0; i < A_F4; ++i) {
     int gr = m0 + row_t + i * RS;
     gr = gr < M ? gr : M - 1;
-    a_src[i] = Af + (size_t)gr * K + kq_t;  // a split-32 row is K dwords long; K tile kt starts at dword 32*kt
+    a_off[i] = ((unsigned)gr * (unsigned)K + kq_t) * 4u;
   }
-  const float* b_base = Wf + (size_t)(n0 + row_t) * K + kq_t;
+#pragma unroll
+  for (int i = 0; i < B_F4; ++i) b_off[i] = ((unsigned)(n0 + row_t + i * RS) * (unsigned)K + kq_t) * 4u;
+#define IKS_BLD(rs, voff, kt_) \
+  __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, __builtin_amdgcn_readfirstlane((kt_) * 128), 0))
   const int lds_t = row_t * LDK + kq_t;
   // fragment of k16-step s, plane p (0 hi, 1 lo): slot p*4 + s*2 + (lane>>5)
   const int fragA = (wm + (lane & 31)) * LDK + (lane >> 5) * 4;
@@ -104,9 +108,8 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
 
 #define IKS_GLOAD(S, kt_)                                                                                          \
   {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[S][i] = *reinterpret_cast<const floatx4*>(a_src[i] + (kt_) * 32); \
-    _Pragma("unroll") for (int i = 0; i < B_F4; ++i)                                                              \
-        rb[S][i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K + (kt_) * 32);                 \
+    _Pragma("unroll") for (int i = 0; i < A_F4; ++i) ra[S][i] = IKS_BLD(rsA, a_off[i], kt_);                       \
+    _Pragma("unroll") for (int i = 0; i < B_F4; ++i) rb[S][i] = IKS_BLD(rsW, b_off[i], kt_);                       \
   }
 #define IKS_LSTORE(S, stage)                                                                                      \
   {                                                                                                               \
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
   {
     floatx4 ra0[A_F4], rb0[B_F4];
 #pragma unroll
-    for (int i = 0; i < A_F4; ++i) ra0[i] = *reinterpret_cast<const floatx4*>(a_src[i]);
+    for (int i = 0; i < A_F4; ++i) ra0[i] = IKS_BLD(rsA, a_off[i], 0);
 #pragma unroll
-    for (int i = 0; i < B_F4; ++i) rb0[i] = *reinterpret_cast<const floatx4*>(b_base + (size_t)(i * RS) * K);
+    for (int i = 0; i < B_F4; ++i) rb0[i] = IKS_BLD(rsW, b_off[i], 0);
     if (KT > 1) IKS_GLOAD(1, 1)
     if (KT > 2) IKS_GLOAD(0, 2)
     float* sp0 = smem + lds_t;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
   }
   IKS_TSTAMP(40)
 #undef IKS_GLOAD
+#undef IKS_BLD
 #undef IKS_LSTORE
 #undef IKS_FRAG
 #undef IKS_MFMA3
