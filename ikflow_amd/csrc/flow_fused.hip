@@ -770,16 +770,8 @@ template <bool EPI_RED, int NH>
 static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = skinny_lds<NH>();
   auto kern = k_flow_gemm_skinny<EPI_RED, NH>;
-  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
-  static bool attr_set[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set[dev_] = true;
-  }
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a);
   return hipGetLastError();
@@ -821,16 +813,8 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
   constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
   constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (FBK + 4) * sizeof(float);
   auto kern = k_flow_gemm<EPI_RED, CFG>;
-  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
-  static bool attr_set[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set[dev_] = true;
-  }
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
   const long long grid = tiles_m * (a.N / TC::BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a);

@@ -465,16 +465,8 @@ static hipError_t launch_gemm_p3(const float* A, const float* W, const float* bi
   constexpr int LDK = BK + 4;
   constexpr size_t smem = (size_t)3 * (BM + BN) * LDK * sizeof(float);
   auto kern = k_gemm_lrelu_p3<BM, BN, BK, WAVES_M, WAVES_N>;
-  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
-  static bool attr_set[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set[dev_] = true;
-  }
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long tiles_m = (M + BM - 1) / BM;
   const long long grid = tiles_m * (N / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), smem, s, A, W, bias, C, (int)M, N, K,
@@ -489,16 +481,8 @@ static hipError_t launch_gemm_t(const float* A, const float* W, const float* bia
   constexpr int LDK = BK + 4;
   constexpr size_t smem = (size_t)2 * (BM + BN) * LDK * sizeof(float);
   auto kern = k_gemm_lrelu<BM, BN, BK, WAVES_M, WAVES_N>;
-  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
-  static bool attr_set[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set[dev_] = true;
-  }
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long tiles_m = (M + BM - 1) / BM;
   const long long grid = tiles_m * (N / BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES_M * WAVES_N * 64), smem, s, A, W, bias, C, (int)M, N, K,

@@ -38,7 +38,7 @@ template <> struct SplitCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M
 template <> struct SplitCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2; };
 template <> struct SplitCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2; };
 constexpr int kNumSplitCfg = 4;
-static const int kSplitBM[kNumSplitCfg] = {128, 64, 64, 32};
+// tile rows per config: {128, 64, 64, 32}
 static const int kSplitBN[kNumSplitCfg] = {128, 128, 64, 64};
 
 template <bool EPI_RED, int CFG>
@@ -541,15 +541,8 @@ template <bool EPI_RED>
 static hipError_t launch_sg_dma(const SplitGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)4 * 256 * 32 * sizeof(float);
   auto kern = k_split_gemm_dma<EPI_RED>;
-  static bool attr_set[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set[dev_] = true;
-  }
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long grid = (((long long)a.M + 127) / 128) * (a.N / 128);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, a);
   return hipGetLastError();
@@ -574,16 +567,8 @@ static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
   using TC = SplitCfg<CFG>;
   constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * 36 * sizeof(float);
   auto kern = k_split_gemm<EPI_RED, CFG>;
-  // the >64 KB dynamic-LDS opt-in is per device: remember which devices of this process already have it
-  static bool attr_set[64] = {};
-  int dev_ = 0;
-  (void)hipGetDevice(&dev_);
-  if (dev_ >= 0 && dev_ < 64 && !attr_set[dev_]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    attr_set[dev_] = true;
-  }
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
   const long long grid = tiles_m * (a.N / TC::BN);
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(TC::WAVES_M * TC::WAVES_N * 64), smem, s, a);

@@ -39,6 +39,19 @@ struct FlowDims {
 };
 
 // flow_kernels.hip
+
+// The > 64 KB dynamic-LDS opt-in (hipFuncAttributeMaxDynamicSharedMemorySize) is per kernel and per device: `done` is
+// the caller's static per-kernel flag array, indexed by the current device.
+template <class Kern>
+inline hipError_t ensure_dynamic_lds(Kern kern, size_t bytes, bool (&done)[64]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || done[dev]) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done[dev] = true;
+  return e;
+}
+
 hipError_t launch_first_layer(const SubnetWeights& w, const FlowDims& d, const float* x_in, int x_off,
                               const PoseSource& ps, long long row0, long long rows, float* h_out, hipStream_t s);
 hipError_t launch_gemm_lrelu(int variant, const float* A, const float* W, const float* bias, float* C, long long M,
