@@ -44,6 +44,32 @@ def test_flow_tiny_matches_oracle(n):
     assert np.abs(got.numpy() - ref64).max() <= FLOW_TOL
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_flow_tiny_every_tile_boundary_and_forced_config(precision):
+    """Row counts on both sides of every tile-picker boundary (256 / 512 / 1024 / 1536 / 2048 rows) in one solver, then
+    the same rows with each tile configuration forced: every contraction kernel, its row clamping and its padded stores
+    against the oracle."""
+    robot, hp, lay, sd = tiny_model()
+    s = _solver(robot, hp, sd)
+    s.set_precision(precision)
+    n_max = 2100
+    _, poses = reachable_poses(robot, n_max, 21)
+    lat = latents(n_max, lay.dim, 22)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
+    for n in (2, 31, 33, 255, 256, 257, 511, 512, 513, 1023, 1025, 1536, 1537, 2048, 2049, 2100):
+        got = s.generate_ik_solutions(poses[:n].to(DEV), latent=lat[:n].to(DEV)).cpu()
+        assert (got - ref[:n]).abs().max().item() <= FLOW_TOL, f"{precision} n={n}"
+    eng = s.engine(DEV)
+    for variant in (101, 102, 103, 104, 105, 107):  # tile configs 0..4 and 6 (ikf_set_gemm_variant)
+        if precision == "f16x3" and variant in (105, 107):
+            continue  # the small-batch kernels are f32-only
+        eng.set_gemm_variant(variant)
+        for n in (1, 100, 300, 700):
+            got = s.generate_ik_solutions(poses[:n].to(DEV), n=(1 if n == 1 else None), latent=lat[:n].to(DEV)).cpu()
+            assert (got - ref[:n]).abs().max().item() <= FLOW_TOL, f"{precision} variant={variant} n={n}"
+    eng.set_gemm_variant(-1)
+
+
 @pytest.mark.parametrize("n,clamp", [(16, True), (500, True), (512, False)])
 def test_flow_panda_matches_oracle(n, clamp):
     got, ref32, ref64 = _flow_case(panda_model(), n, clamp)
