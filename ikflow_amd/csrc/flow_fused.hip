@@ -783,7 +783,11 @@ constexpr int kSkinny32Cfg = 6;  // k_flow_gemm_skinny<.., 1>: 32x32 tiles (5 is
 int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_skinny32_cfg() { return kSkinny32Cfg; }
 int fused_pick_cfg(long long rows, int width) {
-  if (rows <= 512 && width % KBN == 0 && width % (2 * KBK) == 0) return rows <= 256 ? kSkinny32Cfg : kSkinnyCfg;
+  if (width % KBN == 0 && width % (2 * KBK) == 0) {
+    if (rows <= 256) return kSkinny32Cfg;
+    if (rows <= 512) return kSkinnyCfg;
+    if (rows <= 768) return kSkinny32Cfg;  // three co-resident 32x32 workgroups per CU: 1.00 ms against 1.06 (64x64 tiles)
+  }
   // Cost model fitted to the in-chain sweep (tools/cfg_sweep.py -> profiles/r01_cfg_sweep.jsonl; us per contraction at
   // K = 1024, only the ratios matter): the 128x128 and 64x128 tiles run one workgroup per CU, so a launch costs whole
   // rounds of 256 tiles (64.2 / 34 us); two 64x64 workgroups share a CU: 16.5 us per 256 tiles, 19.8 when alone.

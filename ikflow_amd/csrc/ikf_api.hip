@@ -495,7 +495,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   // f16x3 is a throughput mode: up to 256 rows the exact-f32 32x32 small-batch kernel is the faster one (0.55-0.62 ms per
   // call against 0.64-0.69, tools/cfg_sweep.py) and is used instead.  The f16-split kernels always reduce the last Linear
   // in 64-column slots.
-  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && cfg == fused_skinny32_cfg());
+  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && nr <= 256 && cfg == fused_skinny32_cfg());
   const int slots = split ? d.width / 64 : fused_slots(cfg, d.width);
   PendingCoupling pend{};
   pend.P = nullptr;

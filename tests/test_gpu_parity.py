@@ -56,7 +56,7 @@ def test_flow_tiny_every_tile_boundary_and_forced_config(precision):
     _, poses = reachable_poses(robot, n_max, 21)
     lat = latents(n_max, lay.dim, 22)
     ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
-    for n in (2, 31, 33, 255, 256, 257, 511, 512, 513, 1023, 1025, 1536, 1537, 2048, 2049, 2100):
+    for n in (2, 31, 33, 255, 256, 257, 511, 512, 513, 768, 769, 1023, 1025, 1536, 1537, 2048, 2049, 2100):
         got = s.generate_ik_solutions(poses[:n].to(DEV), latent=lat[:n].to(DEV)).cpu()
         assert (got - ref[:n]).abs().max().item() <= FLOW_TOL, f"{precision} n={n}"
     eng = s.engine(DEV)

@@ -22,9 +22,9 @@ for prec in ("f32", "f16x3"):
         poses = torch.randn(B, 7, device="cuda"); poses[:, 3:] /= poses[:, 3:].norm(dim=1, keepdim=True)
         lat = torch.randn(B, layout.dim, device="cuda")
         res = {}
-        for variant in (-1, 101, 102, 103, 104, 105):  # 101 + tile config (ikf_set_gemm_variant)
-            if variant == 105 and (B > 512 or prec != "f32"):
-                continue  # config 4 = small-batch f32 kernel
+        for variant in (-1, 101, 102, 103, 104, 105, 107):  # 101 + tile config (ikf_set_gemm_variant)
+            if variant in (105, 107) and (B > 1024 or prec != "f32"):
+                continue  # configs 4 / 6 = small-batch f32 kernels (32x64 / 32x32 tiles)
             if variant == 104 and B > 2048:
                 continue
             eng.set_gemm_variant(variant)
