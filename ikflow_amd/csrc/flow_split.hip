@@ -38,6 +38,7 @@ template <> struct SplitCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M
 template <> struct SplitCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2; };
 template <> struct SplitCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2; };
 constexpr int kNumSplitCfg = 4;
+constexpr int kSplitSkinnyCfg = 4, kSplitSkinny32Cfg = 6;  // k_split_skinny<.., 2> / <.., 1> (same ids as the f32 pipeline)
 // tile rows per config: {128, 64, 64, 32}
 static const int kSplitBN[kNumSplitCfg] = {128, 128, 64, 64};
 
@@ -548,12 +549,237 @@ static hipError_t launch_sg_dma(const SplitGemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches (<= 512 rows) in the f16-split arithmetic: the structure of k_flow_gemm_skinny (flow_fused.hip) - tile
+// 32 x (NH*32), BK = 128 k per stage, 8 k-slices per stage = NH*8 waves, A rows through two LDS stages, W fragments
+// straight from a fragment-major image (k_wfrag_pack_split) by buffer loads, one barrier per stage, k-slice partial
+// blocks summed through LDS in fixed order.  A wave's slice of a stage is exactly one k16 step: 2 x 16-byte fragment
+// reads (hi, lo planes of its A rows), 2 x buffer_load_dwordx4 (hi, lo planes of its W rows), 3 MFMAs.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SKBM = 32, SKBK = 128, SKKS = 8;
+template <int NH>
+constexpr size_t split_skinny_lds() {
+  return sizeof(float) * ((size_t)SKKS * NH * 16 * 64 + (size_t)(SKBM + 32) * (NH * 32 + 4)) > sizeof(float) * 2 * SKBM * (SKBK + 4)
+             ? sizeof(float) * ((size_t)SKKS * NH * 16 * 64 + (size_t)(SKBM + 32) * (NH * 32 + 4))
+             : sizeof(float) * 2 * SKBM * (SKBK + 4);
+}
+
+template <bool EPI_RED, int NH>
+__global__ __launch_bounds__(NH * SKKS * 64) void k_split_skinny(SplitGemmArgs g) {
+  constexpr int BM = SKBM, BN = NH * 32, BK = SKBK, NT = NH * SKKS * 64, KS = SKKS;
+  constexpr int LDK = BK + 4;           // dwords per LDS row: four 128-B split-32 lines + 16 B pad
+  constexpr int KQ4 = BK / 4;           // 16-byte slots per tile row
+  constexpr int NFA = BM * KQ4 / NT;
+  constexpr int STAGE = BM * LDK;
+  constexpr int LDT = BN + 4;
+  static_assert(BM * KQ4 % NT == 0 && NFA >= 1, "tile/threads mismatch");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BM][LDK] / reduction scratch
+
+  const int M = g.M, N = g.N, K = g.K;
+  const int tiles_n = N / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nh = wave % NH, kq = wave / NH;
+
+  floatx16 am, ac;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { am[r] = 0.f; ac[r] = 0.f; }
+
+  unsigned aoff[NFA];
+  int ldst[NFA];
+#pragma unroll
+  for (int i = 0; i < NFA; ++i) {
+    const int f = t + i * NT, row = f / KQ4, c4 = f - row * KQ4;
+    int gr = m0 + row;
+    gr = gr < M ? gr : M - 1;
+    aoff[i] = ((unsigned)gr * (unsigned)K + c4 * 4) * 4u;  // a split-32 row is K dwords long
+    ldst[i] = row * LDK + c4 * 4;
+  }
+  constexpr int WTILE = KS * 2 * 256;  // dwords per (32-column tile, k tile): 8 k-slices x {hi, lo} x 64 lanes x 16 B
+  const int KT = K / BK;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.A)), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.Wf)), 0, 0x7fffffff, 0x00020000);
+  const unsigned wtile0 = (unsigned)(tn * NH + nh) * KT;
+  const unsigned woff = (unsigned)(kq * (2 * 256) * 4) + lane * 16u;
+  // this wave's k16 step of a stage: line kq/2 of the row, step kq%2 -> hi slot 2*(kq%2) + lane/32, lo slot 4 further
+  const int fragA = (lane & 31) * LDK + (kq >> 1) * 32 + ((kq & 1) * 2 + (lane >> 5)) * 4;
+#define IKQ_LDA(i, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff[i], __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
+#define IKQ_LDW(pl, kt_) __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff + (pl) * 1024, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
+
+  floatx4 rg[NFA];
+  half8 w0[2], w1[2];  // {hi, lo} W fragments of two consecutive tiles
+#pragma unroll
+  for (int i = 0; i < NFA; ++i) rg[i] = IKQ_LDA(i, 0);
+  w0[0] = IKQ_LDW(0, 0);
+  w0[1] = IKQ_LDW(1, 0);
+#pragma unroll
+  for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + ldst[i]) = rg[i];
+  {
+    const int k1 = KT > 1 ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < NFA; ++i) rg[i] = IKQ_LDA(i, k1);
+    w1[0] = IKQ_LDW(0, k1);
+    w1[1] = IKQ_LDW(1, k1);
+  }
+  __syncthreads();
+
+#define IKQ_FRAG(stage)                                                               \
+  {                                                                                   \
+    ah = *reinterpret_cast<const half8*>(smem + (stage) * STAGE + fragA);             \
+    al = *reinterpret_cast<const half8*>(smem + (stage) * STAGE + fragA + 16);        \
+  }
+#define IKQ_PIN __builtin_amdgcn_sched_barrier(0);
+  // iteration kt: the fragments of tile kt are already in (ah, al); A tile kt+1 is written into the other LDS stage (its
+  // readers finished before the previous barrier), tile kt+2 is requested, three MFMAs, then the barrier and the
+  // fragments of tile kt+1.  Branch-free: prefetches past the end re-read the last tile (clamped index).
+#define IKQ_ITER(WC, NXT)                                                             \
+  {                                                                                   \
+    const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;                                   \
+    _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; \
+    _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKQ_LDA(i, k2);           \
+    IKQ_PIN                                                                           \
+    am = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, WC[0], am, 0, 0, 0);              \
+    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, WC[1], ac, 0, 0, 0);              \
+    ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, WC[0], ac, 0, 0, 0);              \
+    WC[0] = IKQ_LDW(0, k2);                                                           \
+    WC[1] = IKQ_LDW(1, k2);                                                           \
+    IKQ_PIN                                                                           \
+    __syncthreads();                                                                  \
+    IKQ_FRAG(NXT)                                                                     \
+    IKQ_PIN                                                                           \
+    ++kt;                                                                             \
+  }
+  half8 ah, al;
+  IKQ_FRAG(0)
+  for (int kt = 0; kt < KT;) {  // KT is even (launcher: K % 256 == 0)
+    IKQ_ITER(w0, 1)
+    IKQ_ITER(w1, 0)
+  }
+#undef IKQ_ITER
+#undef IKQ_PIN
+#undef IKQ_FRAG
+#undef IKQ_LDA
+#undef IKQ_LDW
+  __syncthreads();
+
+  // ---- v = hi*hi + corr/2048 per wave, then the k-slice blocks summed in fixed order kq = 0, 1, .. by all waves
+  float* red = smem;  // [KS][NH][16][64]
+  constexpr float inv_scale = 1.0f / IKF_SPLIT_SCALE;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[((kq * NH + nh) * 16 + r) * 64 + lane] = fmaf(ac[r], inv_scale, am[r]);
+  __syncthreads();
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  float fin[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 2 * kq + j;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) v += red[((q * NH + nh) * 16 + r) * 64 + lane];
+    v += g.bias[n0 + nh * 32 + col_l];
+    fin[j] = v > 0.f ? v : v * g.slope;
+  }
+  if constexpr (!EPI_RED) {
+    // re-split and store: column c of row rl -> hi half at line (c/32), slot c%32; lo half 64 B further
+    char* Cb = reinterpret_cast<char*>(g.C);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * kq + j;
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
+      const int col = n0 + nh * 32 + col_l;
+      const _Float16 hi = (_Float16)fin[j];
+      const _Float16 lo = (_Float16)((fin[j] - (float)hi) * IKF_SPLIT_SCALE);
+      char* p = Cb + (size_t)row * N * 4 + (size_t)(col >> 5) * 128 + (col & 31) * 2;  // row-padded buffer: unpredicated
+      *reinterpret_cast<_Float16*>(p) = hi;
+      *reinterpret_cast<_Float16*>(p + 64) = lo;
+    }
+  } else {
+    float* T = smem + KS * NH * 16 * 64;  // behind red[] (other waves may still be summing)
+    float* Wl = T + BM * LDT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * kq + j;
+      const int rl = (r & 3) + 8 * (r >> 2) + row_h;
+      T[rl * LDT + nh * 32 + col_l] = fin[j];
+    }
+    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
+      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (wave == 0) {  // last Linear restricted to the tile's columns in exact f32 MFMA: one (half) slot per tile
+      floatx16 pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      const float* pa = Wl + (lane & 31) * LDT + (lane >> 5) * 4;
+      const float* pb = T + (lane & 31) * LDT + (lane >> 5) * 4;
+#pragma unroll
+      for (int ks = 0; ks < BN / 8; ++ks) {
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+      }
+      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + row_h;
+        pout[o] = pacc[r];
+      }
+    }
+  }
+}
+
+// fragment-major image of a split-32 [N][K] weight for k_split_skinny: 16-byte unit index
+//   (((tn32*KT + kt)*8 + kq)*2 + plane)*64 + lane
+//      <-  row tn32*32 + lane%32, line kt*4 + kq/2, plane (0 hi / 1 lo), 8 halves of k16 step kq%2, half lane/32
+__global__ __launch_bounds__(256) void k_wfrag_pack_split(const char* __restrict__ Ws, char* __restrict__ out, int N, int K) {
+  const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= (size_t)N * K / 4) return;
+  const int KT = K / SKBK;
+  const int lane = (int)(f & 63);
+  size_t r = f >> 6;
+  const int plane = (int)(r & 1); r >>= 1;
+  const int kq = (int)(r % SKKS); r /= SKKS;
+  const int kt = (int)(r % KT);
+  const int tn32 = (int)(r / KT);
+  const size_t row = (size_t)tn32 * 32 + (lane & 31);
+  const size_t src = row * (size_t)K * 4 + (size_t)(kt * 4 + (kq >> 1)) * 128 + plane * 64 + ((kq & 1) * 2 + (lane >> 5)) * 16;
+  *reinterpret_cast<floatx4*>(out + f * 16) = *reinterpret_cast<const floatx4*>(Ws + src);
+}
+hipError_t launch_wfrag_pack_split(const void* Wsplit, int N, int K, void* out, hipStream_t s) {
+  if (N % 32 != 0 || K % SKBK != 0) return hipErrorInvalidValue;
+  const size_t n4 = (size_t)N * K / 4;
+  hipLaunchKernelGGL(k_wfrag_pack_split, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s,
+                     reinterpret_cast<const char*>(Wsplit), reinterpret_cast<char*>(out), N, K);
+  return hipGetLastError();
+}
+
+template <bool EPI_RED, int NH>
+static hipError_t launch_split_skinny(const SplitGemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = split_skinny_lds<NH>();
+  auto kern = k_split_skinny<EPI_RED, NH>;
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
+  const long long grid = (((long long)a.M + SKBM - 1) / SKBM) * (a.N / (NH * 32));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * SKKS * 64), smem, s, a);
+  return hipGetLastError();
+}
+
 const char* split_kernel_name() { return "k_split_gemm_dma"; }
 
 int split_pick_cfg(long long rows, int width) {
-  // from the in-chain sweep (tools/cfg_sweep.py -> profiles/r01_cfg_sweep.jsonl): 32x64 up to 512 rows, 64x64 up to
-  // 1024, 64x128 up to 2048, and above that the LDS-DMA 128x128 kernel even with idle CUs (2560 rows: 1.31 ms against
-  // 1.72 ms for two rounds of 64x128)
+  // from the in-chain sweep (tools/cfg_sweep.py -> profiles/r01_cfg_sweep.jsonl): the small-batch kernels up to 512 rows
+  // (32x32 tiles up to 256), 64x64 up to 1024, 64x128 up to 2048, and above that the LDS-DMA 128x128 kernel even with
+  // idle CUs (2560 rows: 1.31 ms against 1.72 ms for two rounds of 64x128)
+  if (rows <= 512 && width % 64 == 0 && width % (2 * SKBK) == 0) return rows <= 256 ? kSplitSkinny32Cfg : kSplitSkinnyCfg;
   const int want = rows > 2048 ? 0 : rows > 1024 ? 1 : rows > 512 ? 2 : 3;
   for (int c = want; c < kNumSplitCfg; ++c)
     if (width % kSplitBN[c] == 0) return c;
@@ -561,6 +787,8 @@ int split_pick_cfg(long long rows, int width) {
     if (width % kSplitBN[c] == 0) return c;
   return -1;
 }
+int split_slots(int cfg, int width) { return cfg == kSplitSkinny32Cfg ? width / 32 : width / 64; }
+bool split_cfg_needs_frag(int cfg) { return cfg == kSplitSkinnyCfg || cfg == kSplitSkinny32Cfg; }
 
 template <bool EPI_RED, int CFG>
 static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
@@ -577,6 +805,11 @@ static hipError_t launch_sg(const SplitGemmArgs& a, hipStream_t s) {
 
 hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
+  if (cfg == kSplitSkinnyCfg || cfg == kSplitSkinny32Cfg) {  // small-batch kernels (fragment-major weight image)
+    if (a.N % 64 != 0 || a.K % (2 * SKBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
+    if (cfg == kSplitSkinnyCfg) return epi_red ? launch_split_skinny<true, 2>(a, s) : launch_split_skinny<false, 2>(a, s);
+    return epi_red ? launch_split_skinny<true, 1>(a, s) : launch_split_skinny<false, 1>(a, s);
+  }
   if ((cfg == 10 || cfg == 11) && (a.N % 128 != 0 || a.K % 64 != 0 || a.K < 128 || a.n_out > 16)) return hipErrorInvalidValue;
   if (cfg != 10 && cfg != 11 && (cfg < 0 || cfg >= kNumSplitCfg || a.N % kSplitBN[cfg] != 0 || a.K % 64 != 0 || a.K < 128 || a.n_out > 16)) return hipErrorInvalidValue;
   // config 0 (128x128) runs in its LDS-DMA form; 11 selects the register-staged form of the same tile (probe / A-B)

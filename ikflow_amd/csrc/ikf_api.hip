@@ -36,6 +36,8 @@ struct ikf_model {
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
   uint16_t* split_arena = nullptr;  // split-32 images of the hidden Linear weights
   std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
+  float* split_frag_arena = nullptr;     // fragment-major copies of the split-32 images (small-batch f16-split kernel)
+  std::vector<const void*> w_mid_split_frag;
   float* wfrag_arena = nullptr;          // fragment-major images of the hidden Linear weights (small-batch kernel)
   std::vector<const float*> w_mid_frag;  // [subnet][layer], same flattening; null when the width does not fit
 
@@ -174,6 +176,7 @@ extern "C" void ikf_destroy(ikf_model* m) {
   free_exact(m);
   if (m->arena) (void)hipFree(m->arena);
   if (m->split_arena) (void)hipFree(m->split_arena);
+  if (m->split_frag_arena) (void)hipFree(m->split_frag_arena);
   if (m->wfrag_arena) (void)hipFree(m->wfrag_arena);
   if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
   if (m->d_Minv) (void)hipFree(m->d_Minv);
@@ -235,6 +238,19 @@ static ikf_status build_split_weights(ikf_model* m) {
       IKF_HIP(launch_split32_pack(m->subnets[si].w_mid[l], W, W, dst, nullptr));
       m->w_mid_split[(size_t)si * 3 + l] = dst;
     }
+  // fragment-major copies for the small-batch kernel (same bytes again)
+  m->w_mid_split_frag.assign((size_t)2 * NB * 3, nullptr);
+  if (split_cfg_needs_frag(split_pick_cfg(1, W))) {
+    const size_t per_f = (size_t)W * W;  // dwords
+    IKF_HIP(hipMalloc(&m->split_frag_arena, sizeof(float) * per_f * n_layers));
+    li = 0;
+    for (int si = 0; si < 2 * NB; ++si)
+      for (int l = 0; l < d.n_hidden - 1; ++l, ++li) {
+        float* dstf = m->split_frag_arena + li * per_f;
+        IKF_HIP(launch_wfrag_pack_split(m->w_mid_split[(size_t)si * 3 + l], W, W, dstf, nullptr));
+        m->w_mid_split_frag[(size_t)si * 3 + l] = dstf;
+      }
+  }
   IKF_HIP(hipDeviceSynchronize());
   return IKF_OK;
 }
@@ -391,7 +407,9 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
   m->subnets = subs;
   // the split-32 weight images of the f16-split contraction are built on the device when that mode is selected
   if (m->split_arena) { (void)hipFree(m->split_arena); m->split_arena = nullptr; }
+  if (m->split_frag_arena) { (void)hipFree(m->split_frag_arena); m->split_frag_arena = nullptr; }
   m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
+  m->w_mid_split_frag.assign((size_t)2 * NB * 3, nullptr);
   m->loaded = true;
   if (m->precision == 1) {
     ikf_status sst = build_split_weights(m);
@@ -492,11 +510,14 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
   const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width);
-  // f16x3 is a throughput mode: up to 256 rows the exact-f32 32x32 small-batch kernel is the faster one (0.55-0.62 ms per
-  // call against 0.64-0.69, tools/cfg_sweep.py) and is used instead.  The f16-split kernels always reduce the last Linear
-  // in 64-column slots.
-  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && nr <= 256 && cfg == fused_skinny32_cfg());
-  const int slots = split ? d.width / 64 : fused_slots(cfg, d.width);
+  // f16x3 mode: its own tile choice; the partial-sum slots follow the kernel that writes them
+  const bool split = (m->precision == 1) && m->split_arena != nullptr;
+  int scfg = -1;
+  if (split) {
+    scfg = (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width);
+    if (split_cfg_needs_frag(scfg) && m->split_frag_arena == nullptr) scfg = 3;
+  }
+  const int slots = split ? split_slots(scfg, d.width) : fused_slots(cfg, d.width);
   PendingCoupling pend{};
   pend.P = nullptr;
   const float* x_src = d_latent + (size_t)r0 * d.D;
@@ -525,9 +546,10 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
       if (split) {
         SplitGemmArgs sg{};
         sg.A = cur; sg.C = last ? nullptr : nxt; sg.W = m->w_mid_split[(size_t)(2 * b + which - 1) * 3 + l];
+        sg.Wf = m->w_mid_split_frag.empty() ? nullptr : m->w_mid_split_frag[(size_t)(2 * b + which - 1) * 3 + l];
         sg.bias = w.b_mid[l]; sg.M = (int)nr; sg.N = d.width; sg.K = d.width; sg.slope = d.slope;
         sg.w_last = w.w_last; sg.n_out = w.n_out; sg.P_out = m->pbuf; sg.p_slot_stride = rows_pad * IKF_PSTRIDE;
-        IKF_HIP(launch_split_gemm(last, (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width), sg, s));
+        IKF_HIP(launch_split_gemm(last, scfg, sg, s));
       } else {
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
         g.Wf = m->w_mid_frag[(size_t)(2 * b + which - 1) * 3 + l];

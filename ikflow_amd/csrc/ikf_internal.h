@@ -148,6 +148,7 @@ constexpr float IKF_SPLIT_SCALE = 2048.0f;
 struct SplitGemmArgs {
   const void* A;      // [rows_pad][K] split-32 image
   const void* W;      // [N][K] split-32 image
+  const void* Wf;     // fragment-major image of W for k_split_skinny (launch_wfrag_pack_split), or null
   const float* bias;  // [N]
   void* C;            // [rows_pad][N] split-32 image (unused when the epilogue reduces to partials)
   int M, N, K;
@@ -159,6 +160,9 @@ struct SplitGemmArgs {
 };
 hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s);
 int split_pick_cfg(long long rows, int width);
+int split_slots(int cfg, int width);
+bool split_cfg_needs_frag(int cfg);
+hipError_t launch_wfrag_pack_split(const void* Wsplit, int N, int K, void* out, hipStream_t s);
 void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // host-side packer (probe tool)
 int fused_skinny_cfg();
 int fused_skinny32_cfg();

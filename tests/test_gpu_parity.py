@@ -61,8 +61,6 @@ def test_flow_tiny_every_tile_boundary_and_forced_config(precision):
         assert (got - ref[:n]).abs().max().item() <= FLOW_TOL, f"{precision} n={n}"
     eng = s.engine(DEV)
     for variant in (101, 102, 103, 104, 105, 107):  # tile configs 0..4 and 6 (ikf_set_gemm_variant)
-        if precision == "f16x3" and variant in (105, 107):
-            continue  # the small-batch kernels are f32-only
         eng.set_gemm_variant(variant)
         for n in (1, 100, 300, 700):
             got = s.generate_ik_solutions(poses[:n].to(DEV), n=(1 if n == 1 else None), latent=lat[:n].to(DEV)).cpu()

@@ -23,8 +23,8 @@ for prec in ("f32", "f16x3"):
         lat = torch.randn(B, layout.dim, device="cuda")
         res = {}
         for variant in (-1, 101, 102, 103, 104, 105, 107):  # 101 + tile config (ikf_set_gemm_variant)
-            if variant in (105, 107) and (B > 1024 or prec != "f32"):
-                continue  # configs 4 / 6 = small-batch f32 kernels (32x64 / 32x32 tiles)
+            if variant in (105, 107) and B > 1024:
+                continue  # configs 4 / 6 = small-batch kernels (32x64 / 32x32 tiles)
             if variant == 104 and B > 2048:
                 continue
             eng.set_gemm_variant(variant)
