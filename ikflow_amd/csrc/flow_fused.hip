@@ -52,10 +52,12 @@ static const int kCfgBM[kNumTileCfg] = {128, 64, 64, 32};
 static const int kCfgBN[kNumTileCfg] = {128, 128, 64, 64};
 
 // ---------------------------------------------------------------------------------------------------------------
-// Finish a pending coupling for R rows starting at m0: one thread per (row, state element) sums that element's (s, t)
-// partial-sum slots in fixed order, applies  s = clamp*(0.636*atan s),  y = (x - t)*exp(-s)  and leaves the row
-// [y1 | x2] / [x1 | y2] ("cat", BEFORE PermuteRandom^-1) in LDS cat[R][ROWBUF].  The permutation is applied by the
-// reader through state_src(): new_state[d] = cat[state_src(pc, d)].  Ends with a barrier.
+// Finish a pending coupling for R rows starting at m0.  Phase A: one thread per (row, subnet output o) sums that output's
+// partial-sum slots in fixed order (bias, slot 0, slot 1, ..) - all slot loads of a thread (up to 32) are in flight
+// together, one memory round trip - and parks the sum in LDS.  Phase B: one thread per (row, state element) applies
+// s = clamp*(0.636*atan s),  y = (x - t)*exp(-s)  and leaves the row [y1 | x2] / [x1 | y2] ("cat", BEFORE
+// PermuteRandom^-1) in LDS cat[R][ROWBUF].  The permutation is applied by the reader through state_src():
+// new_state[d] = cat[state_src(pc, d)].  `sums` is an R*ROWBUF-float LDS scratch.  Ends with a barrier.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int state_src(const PendingCoupling& pc, int d) {
   return (pc.P != nullptr && pc.which == 2) ? pc.perm_inv[d] : d;  // PermuteRandom rev: out[:, d] = cat[:, perm_inv[d]]
@@ -63,34 +65,48 @@ __device__ __forceinline__ int state_src(const PendingCoupling& pc, int d) {
 
 template <int NT, int R>
 __device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const float* __restrict__ x_src,
-                                                    int D, int L1, float clamp, int m0, int M, float* cat, int t) {
+                                                    int D, int L1, float clamp, int m0, int M, float* cat, float* sums,
+                                                    int t) {
+  constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
   const int L2 = D - L1;
   // which == 1: y2 = (x2 - t1) * exp(-s1), x1 untouched.   which == 2: y1 = (x1 - t2) * exp(-s2), x2 (= y2) untouched
   const int nl = (pc.which == 1) ? L2 : L1;
   const int off = (pc.which == 1) ? L1 : 0;
-  for (int idx = t; idx < R * ROWBUF; idx += NT) {
-    const int r = idx / ROWBUF, d = idx % ROWBUF;  // ROWBUF is a power of two: shifts
-    if (d >= D) continue;
+  float xv[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {  // the state element of phase B is requested before the slot loads
+    const int idx = t + it * NT, r = idx / ROWBUF, d = idx % ROWBUF;
     int gr = m0 + r;
     gr = gr < M ? gr : M - 1;
-    float v = x_src[(size_t)gr * D + d];
+    xv[it] = (idx < R * ROWBUF && d < D) ? x_src[(size_t)gr * D + d] : 0.f;
+  }
+  if (pc.P != nullptr) {
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = t + it * NT, r = idx / ROWBUF, o = idx % ROWBUF;
+      if (idx >= R * ROWBUF || o >= 2 * nl) continue;
+      const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + o;  // P rows are padded to the tile: no clamp needed
+      float sv = pc.b_last[o];
+      for (int s0 = 0; s0 < pc.slots; s0 += 32) {
+        float a[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) a[q] = (s0 + q < pc.slots) ? p[(size_t)(s0 + q) * pc.slot_stride] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) sv += a[q];
+      }
+      sums[r * ROWBUF + o] = sv;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = t + it * NT, r = idx / ROWBUF, d = idx % ROWBUF;
+    if (idx >= R * ROWBUF || d >= D) continue;
+    float v = xv[it];
     if (pc.P != nullptr && d >= off && d < off + nl) {
       const int j = d - off;
-      const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE;  // P rows are padded to the tile: no clamp needed
-      float sv = pc.b_last[j], tv = pc.b_last[nl + j];
-      for (int s0 = 0; s0 < pc.slots; s0 += 16) {  // 32 independent loads in flight, then fixed-order sums
-        float a[16], b[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const bool ok = s0 + q < pc.slots;
-          a[q] = ok ? p[(size_t)(s0 + q) * pc.slot_stride + j] : 0.f;
-          b[q] = ok ? p[(size_t)(s0 + q) * pc.slot_stride + nl + j] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { sv += a[q]; tv += b[q]; }
-      }
-      const float s_cl = clamp * (0.636f * atanf(sv));
-      v = (v - tv) * expf(-s_cl);
+      const float s_cl = clamp * (0.636f * atanf(sums[r * ROWBUF + j]));
+      v = (v - sums[r * ROWBUF + nl + j]) * expf(-s_cl);
     }
     cat[r * ROWBUF + d] = v;
   }
@@ -105,7 +121,7 @@ constexpr int ER = 16;
 template <int IN>
 __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   constexpr int NT = 256;
-  __shared__ __attribute__((aligned(16))) float cat[ER * ROWBUF], U[ER * ROWBUF];
+  __shared__ __attribute__((aligned(16))) float cat[ER * ROWBUF], U[ER * ROWBUF];  // U doubles as the slot-sum scratch
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * ER;
   const int M = e.M, D = e.D;
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
   }
   IKF_TSTAMP(0)
-  finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, cat, t);
+  finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, cat, U, t);
   IKF_TSTAMP(1)
   // publish the new state and assemble u = [x_part, pose, 0-pad]
   if (blockIdx.y == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
@@ -495,10 +511,10 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
   constexpr int R = 32, NT = 256;
-  __shared__ float cat[R * ROWBUF];
+  __shared__ float cat[R * ROWBUF], sums[R * ROWBUF];
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * R;
-  finish_pending_rows<NT, R>(f.pend, f.x_src, f.D, f.L1, f.clamp, m0, f.M, cat, t);
+  finish_pending_rows<NT, R>(f.pend, f.x_src, f.D, f.L1, f.clamp, m0, f.M, cat, sums, t);
   // FixedLinearTransform rev: (x - b).mm(M_inv); [:, :ndof]; clamp_to_joint_limits
   const int D = f.D;
   for (int idx = t; idx < R * ROWBUF; idx += NT) {
