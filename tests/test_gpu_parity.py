@@ -613,3 +613,28 @@ def test_baseline_sizes_size_independent_properties():
         pe, re = ko.calculate_pose_error(robot, sol[valid], poses[valid])
         assert (pe < 1e-3 * 1.01).all() and (re < 0.01 * 1.01).all()
         assert torch.equal(sol[valid], ko.clamp_to_joint_limits(robot, sol[valid]))
+
+
+def test_one_million_poses_in_one_call():
+    """BASELINE config 5 on one GPU: 1,000,000 target poses through the engine's 16384-row chunking.  Size-independent
+    properties: finite, inside the limits, deterministic; rows around chunk boundaries and at the ends agree with the
+    oracle and with the same rows submitted on their own."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    n = 1_000_000
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lo = torch.tensor([l[0] for l in robot.actuated_joints_limits], device=DEV)
+    hi = torch.tensor([l[1] for l in robot.actuated_joints_limits], device=DEV)
+    q = lo + (hi - lo) * torch.rand((n, 7), generator=g, device=DEV)
+    poses = robot.forward_kinematics(q)
+    lat = torch.randn((n, lay.dim), generator=g, device=DEV)
+    sol = s.generate_ik_solutions(poses, latent=lat)
+    assert sol.shape == (n, 7) and bool(torch.isfinite(sol).all())
+    assert bool(((sol >= lo) & (sol <= hi)).all())
+    assert torch.equal(sol, s.generate_ik_solutions(poses, latent=lat))
+    for start in (0, 16384 - 20, 16384 * 31 - 7, n - 40):
+        sl = slice(start, start + 40)
+        ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[sl].cpu(), lat[sl].cpu())
+        assert (sol[sl].cpu() - ref).abs().max().item() <= FLOW_TOL, f"rows {start}.."
+        alone = s.generate_ik_solutions(poses[sl].contiguous(), latent=lat[sl].contiguous())
+        assert (sol[sl] - alone).abs().max().item() <= FLOW_TOL
