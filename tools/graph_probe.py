@@ -20,7 +20,7 @@ solver.load_state_dict_tensors(random_state_dict(layout, robot, seed=0))
 eng = solver.engine(torch.device("cuda", 0))
 prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
 eng.set_precision(prec)
-for B in (1, 128, 512, 768, 1024, 1536, 2048, 3072, 4096, 8192):
+for B in (1, 128, 256, 512, 1024, 4096):
     eng.reserve(B)
     poses = torch.randn(B, 7, device="cuda"); poses[:, 3:] /= poses[:, 3:].norm(dim=1, keepdim=True)
     lat = torch.randn(B, layout.dim, device="cuda")
