@@ -638,3 +638,29 @@ def test_one_million_poses_in_one_call():
         assert (sol[sl].cpu() - ref).abs().max().item() <= FLOW_TOL, f"rows {start}.."
         alone = s.generate_ik_solutions(poses[sl].contiguous(), latent=lat[sl].contiguous())
         assert (sol[sl] - alone).abs().max().item() <= FLOW_TOL
+
+
+@pytest.mark.parametrize("model_name", ["panda_lite_tpm", "fetch_full_temp_nsc_tpm", "fetch__large__ns183_9.75m"])
+def test_every_released_architecture_matches_oracle(model_name):
+    """The released architectures not covered above (model_descriptions.yaml: 6-block Panda, 12- and 16-block Fetch with
+    D = 8 and the prismatic torso joint): flow and exact-IK entry points against the oracle, seeded weights."""
+    from ikflow_amd.model import MODEL_DESCRIPTIONS, hparams_for, layout_from, random_state_dict
+    from ikflow_amd.robots import get_robot
+
+    robot = get_robot(MODEL_DESCRIPTIONS[model_name]["robot_name"])
+    hp = hparams_for(model_name)
+    lay = layout_from(hp, robot)
+    sd = random_state_dict(lay, robot, seed=4)
+    s = _solver(robot, hp, sd)
+    for n, precision in ((40, "f32"), (600, "f32"), (600, "f16x3")):
+        s.set_precision(precision)
+        _, poses = reachable_poses(robot, n, 50)
+        lat = latents(n, lay.dim, 51)
+        ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat)
+        got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV)).cpu()
+        assert got.shape == (n, robot.ndof)
+        assert (got - ref).abs().max().item() <= FLOW_TOL, f"{model_name} n={n} {precision}"
+    s.set_precision("f32")
+    sol, valid = s.generate_exact_ik_solutions(poses[:64].to(DEV))
+    assert sol.shape == (64, robot.ndof) and valid.shape == (64,) and valid.dtype == torch.bool
+    assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
