@@ -535,6 +535,16 @@ def test_cabi_status_codes_and_edge_sizes():
     assert code == _lib.IKF_ERR_BAD_ARGUMENT  # repeat count 0
     with pytest.raises(EngineError):
         eng.set_gemm_variant(77)
+    # the model-free evaluation helpers
+    pe = torch.zeros(4, device=DEV)
+    lo3, hi3 = (C.c_float * 3)(-1, -2, -3), (C.c_float * 3)(1, 2, 3)
+    ex = torch.zeros(4, dtype=torch.uint8, device=DEV)
+    assert lib.ikf_pose_distance(q.data_ptr(), q.data_ptr(), 4, -1.0, pe.data_ptr(), pe.data_ptr(), stream) == _lib.IKF_OK
+    assert lib.ikf_pose_distance(None, q.data_ptr(), 4, -1.0, pe.data_ptr(), pe.data_ptr(), stream) == _lib.IKF_ERR_NULL_POINTER
+    assert lib.ikf_pose_distance(None, None, 0, -1.0, None, None, stream) == _lib.IKF_OK
+    assert lib.ikf_limits_exceeded(q.data_ptr(), 4, 3, C.cast(lo3, C.c_void_p), C.cast(hi3, C.c_void_p), ex.data_ptr(), stream) == _lib.IKF_OK
+    assert lib.ikf_limits_exceeded(q.data_ptr(), 4, 33, C.cast(lo3, C.c_void_p), C.cast(hi3, C.c_void_p), ex.data_ptr(), stream) == _lib.IKF_ERR_BAD_ARGUMENT
+    assert lib.ikf_limits_exceeded(q.data_ptr(), 4, 3, None, C.cast(hi3, C.c_void_p), ex.data_ptr(), stream) == _lib.IKF_ERR_NULL_POINTER
     # empty exact call through the shim
     s = _solver(robot, hp, sd)
     sol, v = s.generate_exact_ik_solutions(torch.zeros(0, 7, device=DEV))
