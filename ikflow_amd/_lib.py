@@ -13,6 +13,7 @@ IKF_ABI_VERSION = 2
 IKF_MAX_DOF = 8
 IKF_MAX_DIM = 16
 IKF_MAX_ROUNDS = 8
+IKF_MAX_CAPSULES = 24
 
 IKF_OK = 0
 IKF_ERR_NULL_POINTER = 1
@@ -47,6 +48,10 @@ class ikf_model_desc(C.Structure):
     ]
 
 
+class ikf_capsule(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("p0", C.c_float * 3), ("p1", C.c_float * 3), ("radius", C.c_float)]
+
+
 class ikf_tensor(C.Structure):
     _fields_ = [
         ("name", C.c_char_p),
@@ -78,6 +83,8 @@ SIGNATURES = {
     "ikf_jacobian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ikf_clamp_to_joint_limits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ikf_joint_limits_exceeded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "ikf_set_collision_model": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "ikf_self_collision": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ikf_pose_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ikf_limits_exceeded": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ikf_generate_exact": (

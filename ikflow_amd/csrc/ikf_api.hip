@@ -49,6 +49,7 @@ struct ikf_model {
   float* d_Minv = nullptr;             // [D][D]
   float* d_blin = nullptr;             // [D]
   Chain* d_chain = nullptr;            // robot chain + limits
+  CollisionModel* d_collision = nullptr;  // capsules + pairs (ikf_set_collision_model), or null
 
   // scratch
   long long chunk_rows = 0;  // capacity of the per-chunk flow scratch
@@ -182,6 +183,7 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->d_Minv) (void)hipFree(m->d_Minv);
   if (m->d_blin) (void)hipFree(m->d_blin);
   if (m->d_chain) (void)hipFree(m->d_chain);
+  if (m->d_collision) (void)hipFree(m->d_collision);
   if (m->ex_count) (void)hipFree(m->ex_count);
   if (m->h_count) (void)hipHostFree(m->h_count);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
@@ -695,6 +697,45 @@ extern "C" ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, 
   IKF_KIN_PROLOGUE("ikf_joint_limits_exceeded")
   if (!d_q || !d_exceeded_out) return fail(IKF_ERR_NULL_POINTER, "ikf_joint_limits_exceeded: null device pointer");
   IKF_HIP(launch_limits_exceeded(m->d_chain, m->dims.ndof, d_q, n, d_exceeded_out, s));
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_set_collision_model(ikf_model* m, const ikf_capsule* h_capsules, int n_capsules,
+                                              const int32_t* h_pairs, int n_pairs) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_collision_model: null model");
+  if (n_capsules < 0 || n_capsules > IKF_MAX_CAPSULES || n_pairs < 0 || n_pairs > IKF_MAX_CAPSULE_PAIRS)
+    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_collision_model: at most 24 capsules and 276 pairs");
+  if ((n_capsules > 0 && !h_capsules) || (n_pairs > 0 && !h_pairs))
+    return fail(IKF_ERR_NULL_POINTER, "ikf_set_collision_model: null table");
+  CollisionModel cm{};
+  cm.n_caps = n_capsules;
+  cm.n_pairs = n_pairs;
+  for (int c = 0; c < n_capsules; ++c) {
+    if (h_capsules[c].frame < 0 || h_capsules[c].frame > m->dims.ndof || !(h_capsules[c].radius >= 0.f))
+      return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_collision_model: capsule frame must be in [0, ndof] and radius >= 0");
+    cm.frame[c] = h_capsules[c].frame;
+    cm.radius[c] = h_capsules[c].radius;
+    for (int k = 0; k < 3; ++k) { cm.p0[c][k] = h_capsules[c].p0[k]; cm.p1[c][k] = h_capsules[c].p1[k]; }
+  }
+  for (int k = 0; k < n_pairs; ++k) {
+    const int a = h_pairs[2 * k], b = h_pairs[2 * k + 1];
+    if (a < 0 || a >= n_capsules || b < 0 || b >= n_capsules || a == b)
+      return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_collision_model: pair index out of range");
+    cm.pair_a[k] = (uint8_t)a;
+    cm.pair_b[k] = (uint8_t)b;
+  }
+  IKF_HIP(hipSetDevice(m->device));
+  if (!m->d_collision) IKF_HIP(hipMalloc(&m->d_collision, sizeof(CollisionModel)));
+  IKF_HIP(hipMemcpy(m->d_collision, &cm, sizeof(CollisionModel), hipMemcpyHostToDevice));
+  return IKF_OK;
+}
+
+extern "C" ikf_status ikf_self_collision(ikf_model* m, const float* d_q, int64_t n, float* d_min_dist_out,
+                                         uint8_t* d_colliding_out, void* stream) {
+  IKF_KIN_PROLOGUE("ikf_self_collision")
+  if (!m->d_collision) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_self_collision: no collision model has been set");
+  if (!d_q || (!d_min_dist_out && !d_colliding_out)) return fail(IKF_ERR_NULL_POINTER, "ikf_self_collision: null device pointer");
+  IKF_HIP(launch_self_collision(m->d_chain, m->d_collision, m->dims.ndof, d_q, n, d_min_dist_out, d_colliding_out, s));
   return IKF_OK;
 }
 

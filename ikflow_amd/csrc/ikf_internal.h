@@ -178,6 +178,16 @@ struct Chain {
   float lo[IKF_MAX_DOF];
   float hi[IKF_MAX_DOF];
 };
+// IKF_MAX_CAPSULES (24) comes from include/ikflow_amd.h
+constexpr int IKF_MAX_CAPSULE_PAIRS = IKF_MAX_CAPSULES * (IKF_MAX_CAPSULES - 1) / 2;
+struct CollisionModel {
+  int n_caps, n_pairs;
+  int frame[IKF_MAX_CAPSULES];      // 0 = base, j + 1 = the frame that follows actuated joint j
+  float p0[IKF_MAX_CAPSULES][3], p1[IKF_MAX_CAPSULES][3], radius[IKF_MAX_CAPSULES];
+  uint8_t pair_a[IKF_MAX_CAPSULE_PAIRS], pair_b[IKF_MAX_CAPSULE_PAIRS];
+};
+hipError_t launch_self_collision(const Chain* d_chain, const CollisionModel* d_cm, int ndof, const float* q, long long n,
+                                 float* min_dist, uint8_t* colliding, hipStream_t s);
 hipError_t launch_fk(const Chain* d_chain, int ndof, const float* q, long long n, float* poses, hipStream_t s);
 hipError_t launch_pose_error(const Chain* d_chain, int ndof, const float* q, const float* targets, long long n,
                              float* pos_err, float* rot_err, hipStream_t s);

@@ -368,6 +368,80 @@ __global__ __launch_bounds__(256) void k_limits_exceeded_table(LimitsTable t, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Capsule self-collision (the mechanism behind evaluation_utils.calculate_self_collisions, ikflow/evaluation_utils.py:
+// 115-126, which the reference delegates to jrl/Klampt).  Capsules live in the frame that follows an actuated joint
+// (frame 0 = base, frame j+1 = after joint j; fixed URDF offsets are folded on the host); a configuration collides when
+// a listed capsule pair comes closer than the sum of its radii.  One thread per row; closest points of two segments
+// after Ericson, "Real-Time Collision Detection", 5.1.9.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float segment_segment_dist(const float* p1, const float* q1, const float* p2, const float* q2) {
+  const float d1[3] = {q1[0] - p1[0], q1[1] - p1[1], q1[2] - p1[2]};
+  const float d2[3] = {q2[0] - p2[0], q2[1] - p2[1], q2[2] - p2[2]};
+  const float r[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const float a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2];
+  const float e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+  const float f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+  const float EPS = 1e-12f;
+  float sN, tN;
+  if (a <= EPS && e <= EPS) {
+    sN = 0.f; tN = 0.f;
+  } else if (a <= EPS) {
+    sN = 0.f; tN = fminf(fmaxf(f / e, 0.f), 1.f);
+  } else {
+    const float c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2];
+    if (e <= EPS) {
+      tN = 0.f; sN = fminf(fmaxf(-c / a, 0.f), 1.f);
+    } else {
+      const float b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+      const float denom = a * e - b * b;
+      sN = denom > EPS ? fminf(fmaxf((b * f - c * e) / denom, 0.f), 1.f) : 0.f;
+      tN = (b * sN + f) / e;
+      if (tN < 0.f) { tN = 0.f; sN = fminf(fmaxf(-c / a, 0.f), 1.f); }
+      else if (tN > 1.f) { tN = 1.f; sN = fminf(fmaxf((b - c) / a, 0.f), 1.f); }
+    }
+  }
+  const float dx = r[0] + d1[0] * sN - d2[0] * tN, dy = r[1] + d1[1] * sN - d2[1] * tN, dz = r[2] + d1[2] * sN - d2[2] * tN;
+  return sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+template <int NDOF>
+__global__ __launch_bounds__(64) void k_self_collision(const Chain* __restrict__ ch, const CollisionModel* __restrict__ cm,
+                                                       const float* __restrict__ q, long long n,
+                                                       float* __restrict__ min_dist, uint8_t* __restrict__ colliding) {
+  __shared__ float W[64][IKF_MAX_CAPSULES * 6 + 1];  // world end points of this thread's capsules (+1: bank spread)
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float* w = W[threadIdx.x];
+  float qv[NDOF];
+  load_q<NDOF>(q, row, qv);
+  float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, p[3] = {0.f, 0.f, 0.f};
+  const int nc = cm->n_caps;
+  for (int f = 0; f <= NDOF; ++f) {
+    if (f > 0) {
+      compose<float>(R, p, ch->joints[f - 1].pre);
+      apply_joint<float>(R, p, ch->joints[f - 1].kind, ch->joints[f - 1].axis, qv[f - 1]);
+    }
+    for (int c = 0; c < nc; ++c) {
+      if (cm->frame[c] != f) continue;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float* pl = e == 0 ? cm->p0[c] : cm->p1[c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) w[c * 6 + e * 3 + r] = R[3 * r + 0] * pl[0] + R[3 * r + 1] * pl[1] + R[3 * r + 2] * pl[2] + p[r];
+      }
+    }
+  }
+  float best = 3.0e38f;
+  for (int k = 0; k < cm->n_pairs; ++k) {
+    const int a = cm->pair_a[k], b = cm->pair_b[k];
+    const float d = segment_segment_dist(w + a * 6, w + a * 6 + 3, w + b * 6, w + b * 6 + 3) - cm->radius[a] - cm->radius[b];
+    best = fminf(best, d);
+  }
+  if (min_dist) min_dist[row] = best;
+  if (colliding) colliding[row] = best < 0.f ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // exact-IK round kernels.  Row layout of q is the reference's tile-major one: row = r * n_active + j  <->  repeat r of
 // active pose j (cond.repeat((R,1)), ikflow_solver.py:185).  Poses solved in an earlier iteration are masked instead
 // of physically compacted (rows are independent, so the results are identical to the reference's q[mask] compaction).
@@ -504,6 +578,13 @@ hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int nc
   LimitsTable t{};
   for (int j = 0; j < ncols; ++j) { t.lo[j] = lo[j]; t.hi[j] = hi[j]; }
   hipLaunchKernelGGL(k_limits_exceeded_table, dim3(blocks_for(n, 256)), dim3(256), 0, s, t, ncols, q, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_self_collision(const Chain* ch, const CollisionModel* cm, int ndof, const float* q, long long n,
+                                 float* min_dist, uint8_t* colliding, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_self_collision<ND>), dim3(blocks_for(n, 64)), dim3(64), 0, s, ch, cm, q, n,
+                                             min_dist, colliding));
   return hipGetLastError();
 }
 hipError_t launch_exact_lm_iter(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active,

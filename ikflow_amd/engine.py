@@ -244,6 +244,28 @@ class Engine:
             _check(self.lib.ikf_joint_limits_exceeded(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
         return out.to(torch.bool)
 
+    # -- capsule self-collision (evaluation_utils.calculate_self_collisions mechanism) ------------------------
+    def set_collision_model(self, capsules, pairs) -> None:
+        """capsules: [(frame, p0[3], p1[3], radius)] in engine frames (0 = base, j + 1 = after actuated joint j);
+        pairs: [(a, b)] capsule indices."""
+        arr = (_lib.ikf_capsule * max(len(capsules), 1))()
+        for c, (frame, p0, p1, r) in zip(arr, capsules):
+            c.frame, c.radius = int(frame), float(r)
+            for k in range(3):
+                c.p0[k], c.p1[k] = float(p0[k]), float(p1[k])
+        flat = (C.c_int32 * max(2 * len(pairs), 1))(*[int(v) for ab in pairs for v in ab])
+        _check(self.lib.ikf_set_collision_model(self._h, C.cast(arr, C.c_void_p), len(capsules), C.cast(flat, C.c_void_p), len(pairs)))
+        self._has_collision_model = True
+
+    def self_collision(self, q: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """[n x ndof] -> (signed clearance of the closest pair [n] f32, colliding [n] bool)."""
+        q = self._q(q)
+        dist = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
+        col = torch.empty(q.shape[0], dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.ikf_self_collision(self._h, q.data_ptr(), q.shape[0], dist.data_ptr(), col.data_ptr(), self._stream()))
+        return dist, col.to(torch.bool)
+
     # -- exact IK ------------------------------------------------------------------------------------
     def generate_exact(
         self,

@@ -5,8 +5,10 @@ Same function names, argument meaning and return shapes as the reference; the ar
 accepts them (``PT_NP_TYPE``) and are returned as numpy; torch inputs come back on the device they arrived on.
 There is no CPU path: without a GPU every function raises ``EngineError``.
 
-Not reproduced: ``calculate_self_collisions`` (evaluation_utils.py:115-126 calls Klampt through jrl, neither is
-available) - it raises ``NotImplementedError`` and ``evaluate_solutions`` returns ``None`` in that slot.
+``calculate_self_collisions`` (evaluation_utils.py:115-126 calls Klampt through jrl, neither is available)
+runs the engine's capsule test when the robot carries a capsule model (``Robot.set_collision_capsules`` - no geometry
+ships with the built-in robots); otherwise it raises ``NotImplementedError`` and ``evaluate_solutions`` returns ``None``
+in that slot.
 """
 from __future__ import annotations
 
@@ -110,9 +112,14 @@ def calculate_joint_limits_exceeded(configs: torch.Tensor, joint_limits: List[Tu
 
 
 def calculate_self_collisions(robot: Robot, configs: torch.Tensor) -> torch.Tensor:
-    raise NotImplementedError(
-        "self-collision checking needs jrl's Klampt collision model (evaluation_utils.py:115-126), which is not available"
-    )
+    """[batch] bools from the robot's capsule model (evaluation_utils.py:115-126 asks jrl / Klampt per configuration).
+    The built-in robots carry no collision geometry: attach one with ``Robot.set_collision_capsules`` first."""
+    if not robot.has_collision_model:
+        raise NotImplementedError(
+            "self-collision checking needs a collision model (jrl's is not available here): Robot.set_collision_capsules(...)"
+        )
+    dev = configs.device if configs.is_cuda else _device()
+    return robot.config_self_collides(configs.to(dev)).to(configs.device)
 
 
 def evaluate_solutions(robot: Robot, target_poses: PT_NP_TYPE, solutions: torch.Tensor):
@@ -123,4 +130,5 @@ def evaluate_solutions(robot: Robot, target_poses: PT_NP_TYPE, solutions: torch.
     target_poses = _get_target_pose_batch(target_poses, solutions.shape[0])
     l2_errors, angular_errors = solution_pose_errors(robot, solutions, target_poses)
     joint_limits_exceeded = calculate_joint_limits_exceeded(solutions, robot.actuated_joints_limits)
-    return l2_errors, angular_errors, joint_limits_exceeded, None
+    self_collisions = calculate_self_collisions(robot, solutions) if robot.has_collision_model else None
+    return l2_errors, angular_errors, joint_limits_exceeded, self_collisions

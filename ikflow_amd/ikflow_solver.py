@@ -139,7 +139,10 @@ class IKFlowSolver:
             targets = y.reshape(1, 7).expand(n, 7).contiguous() if y.numel() == 7 else y
             pos_errors, rot_errors = eng.pose_error(solutions, targets)
             joint_limits_exceeded = eng.joint_limits_exceeded(solutions)
-            return solutions, pos_errors, rot_errors, joint_limits_exceeded, None, time() - t0
+            # evaluation_utils.evaluate_solutions' fourth slot: filled when the robot carries a capsule model (jrl's
+            # collision geometry is not available here), None otherwise
+            self_colliding = self._robot.config_self_collides(solutions) if self._robot.has_collision_model else None
+            return solutions, pos_errors, rot_errors, joint_limits_exceeded, self_colliding, time() - t0
         return solutions
 
     def _calculate_pose_error(self, qs: torch.Tensor, target_poses: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -141,6 +141,66 @@ class Robot:
         """[n x ndof] -> [n x 6 x ndof] geometric Jacobian, rows = [angular(3); linear(3)]."""
         return self._engine(q).jacobian(q)
 
+    # -- capsule self-collision model (jrl.Robot.config_self_collides / self_collision_distances mechanism) ---------
+    def set_collision_capsules(self, capsules, ignored_pairs=()):
+        """Attach a capsule collision model.  No geometry ships with the built-in robots: jrl's capsule tables are not
+        part of this repository, so the caller supplies them.
+
+        capsules: sequence of ``(after_joint, p0, p1, radius)`` - a segment p0-p1 (metres) with a radius, expressed in the
+        URDF frame of the child link of joint ``after_joint`` (a joint name of this chain, actuated or fixed), or
+        ``None`` for the base link.  ignored_pairs: capsule index pairs that are never tested (adjacent links);
+        capsules riding on the same moving frame are never tested against each other.
+        """
+        names = [j.name for j in self._joints]
+        folded = []
+        for after, p0, p1, radius in capsules:
+            T = np.eye(4)
+            frame = 0
+            if after is not None:
+                assert after in names, f"unknown joint '{after}' (chain joints: {names})"
+                for j in self._joints[: names.index(after) + 1]:
+                    if j.actuated:
+                        frame += 1
+                        T = np.eye(4)  # the engine frame follows the joint's motion; later fixed origins accumulate below
+                    else:
+                        F = np.eye(4)
+                        F[:3, :3] = rpy_to_matrix(j.origin_rpy)
+                        F[:3, 3] = j.origin_xyz
+                        T = T @ F
+            a = (T @ np.array([*p0, 1.0], dtype=np.float64))[:3]
+            b = (T @ np.array([*p1, 1.0], dtype=np.float64))[:3]
+            folded.append((frame, tuple(a), tuple(b), float(radius)))
+        ignored = {tuple(sorted((int(a), int(b)))) for a, b in ignored_pairs}
+        pairs = [(a, b) for a in range(len(folded)) for b in range(a + 1, len(folded))
+                 if folded[a][0] != folded[b][0] and (a, b) not in ignored]
+        self._collision_model = (folded, pairs)
+        return self
+
+    @property
+    def has_collision_model(self) -> bool:
+        return getattr(self, "_collision_model", None) is not None
+
+    def _collision_engine(self, q):
+        assert self.has_collision_model, "no capsule collision model: call Robot.set_collision_capsules(...) first"
+        eng = self._engine(q)
+        if getattr(eng, "_collision_source", None) is not self._collision_model:
+            eng.set_collision_model(*self._collision_model)
+            eng._collision_source = self._collision_model
+        return eng
+
+    def self_collision_distances(self, q):
+        """[n x ndof] -> [n] signed clearance of the closest tested capsule pair (negative = overlapping)."""
+        return self._collision_engine(q).self_collision(q)[0]
+
+    def config_self_collides(self, q):
+        """[n x ndof] -> [n] bool (one configuration [ndof] -> Python bool, like jrl.Robot.config_self_collides)."""
+        import torch
+
+        single = getattr(q, "ndim", 2) == 1
+        qq = q.reshape(1, -1) if single else q
+        col = self._collision_engine(qq).self_collision(qq)[1]
+        return bool(col[0].item()) if single else col
+
 
 _HALF_PI = math.pi / 2.0
 

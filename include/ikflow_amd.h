@@ -126,6 +126,25 @@ ikf_status ikf_clamp_to_joint_limits(ikf_model* m, const float* d_q, int64_t n, 
 ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, int64_t n, uint8_t* d_exceeded_out,
                                      void* stream);
 
+/* Capsule self-collision: the mechanism behind evaluation_utils.calculate_self_collisions (ikflow/evaluation_utils.py:
+ * 115-126; the reference delegates to jrl / Klampt, whose collision geometry is not part of this repository - the caller
+ * supplies the capsules).  A capsule is a segment p0-p1 with a radius, expressed in the frame that follows an actuated
+ * joint: frame 0 = base, frame j + 1 = after actuated joint j (0-based), fixed URDF offsets already folded in.
+ * pairs = 2 * n_pairs capsule indices; a configuration collides when any listed pair is closer than r_a + r_b. */
+typedef struct ikf_capsule {
+  int32_t frame;
+  float p0[3];
+  float p1[3];
+  float radius;
+} ikf_capsule;
+#define IKF_MAX_CAPSULES 24
+ikf_status ikf_set_collision_model(ikf_model* m, const ikf_capsule* h_capsules, int n_capsules, const int32_t* h_pairs,
+                                   int n_pairs);
+/* [n x ndof] -> signed clearance of the closest listed pair (d_min_dist_out, nullable) and the collision flag
+ * (d_colliding_out, nullable).  IKF_ERR_BAD_ARGUMENT when no collision model has been set. */
+ikf_status ikf_self_collision(ikf_model* m, const float* d_q, int64_t n, float* d_min_dist_out, uint8_t* d_colliding_out,
+                              void* stream);
+
 /* Model-free helpers of the evaluation path, on the current device.
  * evaluation_utils.pose_errors (ikflow/evaluation_utils.py:37-51): [n x 7] vs [n x 7] -> L2 position error and
  * quaternion geodesic; acos_epsilon < 0 selects the jrl default (1e-7). */

@@ -275,3 +275,79 @@ def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torc
         if new_sol.all():  # quirk Q3 (ikflow_solver.py:402)
             return solutions, valids
     return solutions, valids
+
+
+# ---------------------------------------------------------------------------------------------------
+# capsule self-collision (checker of ikf_self_collision; float64 numpy, brute-force closest points on a parameter grid
+# refined by the closed form - no shared code with the kernel)
+# ---------------------------------------------------------------------------------------------------
+def _link_frames(robot: Robot, q: torch.Tensor):
+    """World transforms [n x 4 x 4] of the base (index 0) and of the frame that follows each actuated joint (1..ndof),
+    walking the URDF joints one by one (fixed joints included) in float64."""
+    qd = q.double()
+    n = qd.shape[0]
+    T = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
+    frames = [T.clone()]
+    k = 0
+    per_joint = []
+    for j in robot.joints:
+        T = T @ _fixed_T(j, torch.float64)
+        if j.actuated:
+            M = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
+            ax = torch.tensor(j.axis, dtype=torch.float64)
+            ax = ax / ax.norm()
+            if j.kind == 1:
+                M[:, :3, :3] = axis_angle_to_matrix(ax.tolist(), qd[:, k])
+            else:
+                M[:, :3, 3] = ax[None, :] * qd[:, k : k + 1]
+            T = T @ M
+            k += 1
+        per_joint.append(T.clone())
+    return per_joint
+
+
+def capsule_clearance(robot: Robot, capsules, ignored_pairs, q: torch.Tensor) -> torch.Tensor:
+    """capsules in URDF link frames, as given to Robot.set_collision_capsules.  Returns [n] float64: min over tested pairs
+    of (segment distance - r_a - r_b)."""
+    names = [j.name for j in robot.joints]
+    per_joint = _link_frames(robot, q)
+    n = q.shape[0]
+    ends, radii, moving = [], [], []
+    for after, p0, p1, r in capsules:
+        T = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1) if after is None else per_joint[names.index(after)]
+        a = (T @ torch.tensor([*p0, 1.0], dtype=torch.float64))[:, :3]
+        b = (T @ torch.tensor([*p1, 1.0], dtype=torch.float64))[:, :3]
+        ends.append((a, b))
+        radii.append(float(r))
+        moving.append(0 if after is None else sum(1 for j in robot.joints[: names.index(after) + 1] if j.actuated))
+    ignored = {tuple(sorted(p)) for p in ignored_pairs}
+    best = torch.full((n,), float("inf"), dtype=torch.float64)
+    grid = torch.linspace(0.0, 1.0, 201, dtype=torch.float64)
+    for i in range(len(capsules)):
+        for k in range(i + 1, len(capsules)):
+            if moving[i] == moving[k] or (i, k) in ignored:
+                continue
+            (a0, a1), (b0, b1) = ends[i], ends[k]
+            # brute force over s on a grid, exact t for each s (point-to-segment), then polish s by golden section
+            def dist_for_s(sv):
+                pa = a0[:, None, :] + (a1 - a0)[:, None, :] * sv[..., None]
+                d2 = b1 - b0
+                e = (d2 * d2).sum(-1).clamp_min(1e-300)
+                tt = (((pa - b0[:, None, :]) * d2[:, None, :]).sum(-1) / e[:, None]).clamp(0.0, 1.0)
+                pb = b0[:, None, :] + d2[:, None, :] * tt[..., None]
+                return (pa - pb).norm(dim=-1)
+            d = dist_for_s(grid[None, :].expand(n, -1))
+            i0 = d.argmin(dim=1)
+            lo = grid[(i0 - 1).clamp_min(0)]
+            hi = grid[(i0 + 1).clamp_max(200)]
+            for _ in range(60):
+                m1 = lo + (hi - lo) * 0.381966011250105
+                m2 = lo + (hi - lo) * 0.618033988749895
+                f1 = dist_for_s(m1[:, None])[:, 0]
+                f2 = dist_for_s(m2[:, None])[:, 0]
+                take = f1 < f2
+                hi = torch.where(take, m2, hi)
+                lo = torch.where(take, lo, m1)
+            dmin = torch.minimum(d.min(dim=1).values, dist_for_s(((lo + hi) / 2)[:, None])[:, 0])
+            best = torch.minimum(best, dmin - radii[i] - radii[k])
+    return best

@@ -674,3 +674,57 @@ def test_every_released_architecture_matches_oracle(model_name):
     sol, valid = s.generate_exact_ik_solutions(poses[:64].to(DEV))
     assert sol.shape == (64, robot.ndof) and valid.shape == (64,) and valid.dtype == torch.bool
     assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
+
+
+@pytest.mark.parametrize("which", ["panda", "fetch"])
+def test_capsule_self_collision_matches_oracle(which):
+    """ikf_self_collision (mechanism of evaluation_utils.calculate_self_collisions) against the float64 oracle: capsules on
+    the base, on links behind actuated joints and behind fixed joints (folded on the host), random configurations."""
+    from ikflow_amd import evaluation_utils as eu
+    from ikflow_amd.robots import get_robot
+
+    robot = get_robot(which)
+    names = [j.name for j in robot.joints]
+    act = [j.name for j in robot.joints if j.actuated]
+    rng = np.random.default_rng(11)
+    capsules = [(None, (0.0, 0.0, 0.0), (0.0, 0.0, 0.25), 0.07)]
+    for nm in (act[1], act[3], act[5], names[-1]):  # names[-1] is a fixed joint (hand / gripper)
+        p0 = tuple(rng.uniform(-0.08, 0.08, 3))
+        p1 = tuple(rng.uniform(-0.15, 0.15, 3))
+        capsules.append((nm, p0, p1, float(rng.uniform(0.03, 0.08))))
+    capsules.append((act[5], (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.05))  # a sphere (degenerate segment)
+    ignored = [(0, 1)]
+    robot.set_collision_capsules(capsules, ignored_pairs=ignored)
+    n = 3000
+    q = torch.tensor(robot.sample_joint_angles(n, 0.0, rng))
+    ref = ko.capsule_clearance(robot, capsules, ignored, q)
+    dist = robot.self_collision_distances(q.to(DEV)).cpu().double()
+    assert (dist - ref).abs().max().item() <= 2e-5, (dist - ref).abs().max().item()
+    col = robot.config_self_collides(q.to(DEV)).cpu()
+    clear = ref.abs() > 1e-4  # flags must agree wherever the clearance is not within rounding of zero
+    assert torch.equal(col[clear], (ref < 0)[clear])
+    assert 0 < int(col.sum()) < n  # the random model produces both outcomes
+    assert robot.config_self_collides(q[0].to(DEV)) == bool(col[0])
+    # evaluate_solutions fills the fourth slot once a collision model is attached
+    poses = robot.forward_kinematics(q[:50].to(DEV))
+    out = eu.evaluate_solutions(robot, poses, q[:50].to(DEV))
+    assert out[3] is not None and torch.equal(out[3].cpu(), col[:50])
+    if which == "panda":  # the solver's return_detailed tuple carries the flags too
+        _, hp, lay, sd = tiny_model()
+        sv = IKFlowSolver(hp, robot)
+        sv.load_state_dict_tensors(sd)
+        det = sv.generate_ik_solutions(poses, latent=latents(50, lay.dim, 3).to(DEV), return_detailed=True)
+        assert det[4] is not None and det[4].dtype == torch.bool and det[4].shape == (50,)
+        assert torch.equal(det[4], robot.config_self_collides(det[0]))
+    # C-ABI errors: no model set -> BAD_ARGUMENT; bad frame / pair -> BAD_ARGUMENT
+    from ikflow_amd import _lib
+    from ikflow_amd.engine import Engine, EngineError
+    from ikflow_amd.model import FlowLayout
+
+    eng = Engine(FlowLayout(nb_nodes=1, dim=max(robot.ndof, 2), dim_cond=8, width=256, n_hidden=1, clamp=2.5, ndof=robot.ndof), robot, DEV)
+    with pytest.raises(EngineError, match="no collision model"):
+        eng.self_collision(q[:4].to(DEV))
+    with pytest.raises(EngineError, match="frame"):
+        eng.set_collision_model([(robot.ndof + 1, (0, 0, 0), (0, 0, 1), 0.1)], [])
+    with pytest.raises(EngineError, match="pair"):
+        eng.set_collision_model([(0, (0, 0, 0), (0, 0, 1), 0.1)], [(0, 0)])

@@ -207,3 +207,21 @@ def test_evaluation_utils_host_side():
             eu.pose_errors(batch, batch)
         with pytest.raises(EngineError):
             eu.calculate_joint_limits_exceeded(torch.zeros(2, 3), [(-1, 1)] * 3)
+
+
+def test_collision_capsule_folding_and_pairs():
+    """Robot.set_collision_capsules: fixed URDF offsets folded into the frame of the preceding actuated joint; pairs = all
+    capsule pairs on different moving frames minus the ignored ones."""
+    robot = Panda()
+    assert not robot.has_collision_model
+    caps = [(None, (0, 0, 0), (0, 0, 0.3), 0.06), ("panda_joint7", (0, 0, 0), (0, 0, 0.05), 0.04),
+            ("panda_joint8", (0, 0, 0), (0, 0, 0.05), 0.04), ("panda_hand_joint", (0.01, 0, 0), (0.01, 0, 0.05), 0.03)]
+    robot.set_collision_capsules(caps, ignored_pairs=[(1, 0)])
+    folded, pairs = robot._collision_model
+    assert [f[0] for f in folded] == [0, 7, 7, 7]
+    np.testing.assert_allclose(folded[2][1], (0, 0, 0.107), atol=1e-12)  # panda_joint8 origin (fixed, z = 0.107)
+    c, s_ = np.cos(-np.pi / 4), np.sin(-np.pi / 4)  # panda_hand_joint: rpy (0, 0, -pi/4) behind joint8
+    np.testing.assert_allclose(folded[3][1], (c * 0.01, s_ * 0.01, 0.107), atol=1e-12)
+    assert pairs == [(0, 2), (0, 3)]  # (0,1) ignored; 1, 2, 3 ride on the same frame
+    with pytest.raises(AssertionError):
+        robot.set_collision_capsules([("no_such_joint", (0, 0, 0), (0, 0, 1), 0.1)])
