@@ -45,6 +45,9 @@ def parse():
                    help="arithmetic of the hidden contractions: exact-f32 MFMA, or the error-compensated 3x f16 MFMA split")
     p.add_argument("--no-split-extra", action="store_true", help="skip the extra f16x3 measurement")
     p.add_argument("--extras", action="store_true", help="also time B=512 approx and exact IK (reported under `extra`)")
+    p.add_argument("--million", action="store_true",
+                   help="BASELINE config 5: 1,000,000 target poses per step sharded over the ranks (batch = 1e6 / world), "
+                        "one all-gather per step")
     return p.parse_args()
 
 
@@ -137,6 +140,8 @@ def main():
     if args.precision != "f32":
         solver.set_precision(args.precision)
 
+    if args.million:
+        args.batch = (1_000_000 + world - 1) // world
     B = args.batch
     # poses = FK(q), q ~ U(lo+eps, hi-eps), numpy default_rng(seed); latents N(0,1)
     q = torch.tensor(robot.sample_joint_angles(B, 0.004363323129985824, np.random.default_rng(rank)), device=dev)
@@ -190,11 +195,15 @@ def main():
     # dominant kernel: per-launch HIP-event timing (on the engine's stream) of every hidden-Linear contraction inside
     # a few more, otherwise identical, steps
     eng.profile_begin()
-    for _ in range(min(10, max(2, args.steps))):
+    gemm_layers = 2 * layout.nb_nodes * (layout.n_hidden - 1)
+    chunks = (B + 16383) // 16384  # the engine processes a call in chunks of <= 16384 rows
+    prof_steps = max(1, min(10, max(2, args.steps), 8000 // (gemm_layers * chunks)))  # the event pool holds 8192 pairs
+    for _ in range(prof_steps):
         step()
     n_launch, tot_ms = eng.profile_end()
     gemm_ms = tot_ms / max(n_launch, 1)
-    flop_per_launch = 2.0 * B * layout.width * layout.width
+    # every hidden layer processes all B rows of a step, in one launch (B <= 16384) or in 16384-row chunks
+    flop_per_launch = prof_steps * gemm_layers * 2.0 * B * layout.width * layout.width / max(n_launch, 1)
     achieved = flop_per_launch / (gemm_ms * 1e-3) / 1e12
     value = world * B * args.steps / elapsed
     flow_tflops = value / world * layout.flops_per_solution() / 1e12
