@@ -24,6 +24,12 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_W
   cp "$(find /tmp/pmc_${R}_$i -name '*counter_collection.csv' | head -1)" "/tmp/pmc_${R}_$i.csv"
 done
 python "$REPO/tools/pmc_summarize.py" "$OUT/pmc_summary.json" k_flow_gemm /tmp/pmc_${R}_1.csv /tmp/pmc_${R}_2.csv /tmp/pmc_${R}_3.csv
+# SQ / LDS counters of the other regimes' kernels (f16x3 LDS-DMA kernel, small-batch kernels)
+for V in "f16x3:--precision f16x3:k_split_gemm" "b128:--batch 128:k_flow_gemm_skinny"; do
+  TAG=${V%%:*}; REST=${V#*:}; FLAGS=${REST%%:*}; KERN=${REST#*:}
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_${R}_$TAG -o p --output-format csv -- $SHORT $FLAGS > "$OUT/pmc_$TAG.log" 2>&1
+  python "$REPO/tools/pmc_summarize.py" "$OUT/pmc_summary_$TAG.json" $KERN "$(find /tmp/pmc_${R}_$TAG -name '*counter_collection.csv' | head -1)"
+done
 cd "$REPO"
 mkdir -p profiles && cp "$OUT/pmc_summary.json" "profiles/${R}_pmc_summary.json"   # so the bench below reports this traffic
 python bench.py > "$OUT/bench_default.log" 2>&1; tail -1 "$OUT/bench_default.log" > "$OUT/bench_default.json"
