@@ -225,3 +225,21 @@ def test_collision_capsule_folding_and_pairs():
     assert pairs == [(0, 2), (0, 3)]  # (0,1) ignored; 1, 2, 3 ride on the same frame
     with pytest.raises(AssertionError):
         robot.set_collision_capsules([("no_such_joint", (0, 0, 0), (0, 0, 1), 0.1)])
+
+
+def test_bench_and_entry_contract_host_side(monkeypatch):
+    """bench.py defaults (N = 1, a K / W that finish within minutes, the BASELINE batch), the committed PMC summary it
+    reports `roofline.traffic` from, and the two driver entry points."""
+    import sys
+
+    import bench
+
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse()
+    assert (a.gpus, a.batch, a.precision, a.million) == (1, 4096, "f32", False) and 0 < a.warmup < a.steps <= 100
+    traffic, src = bench.pmc_traffic_per_launch()
+    assert isinstance(traffic, int) and traffic > 21_000_000 and src.endswith("_pmc_summary.json")
+    assert bench.FP32_MFMA_PEAK_TFLOPS == 157.3
+    import __graft_entry__ as ge
+
+    assert callable(ge.build) and callable(ge.smoke)
