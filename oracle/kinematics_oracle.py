@@ -1,4 +1,4 @@
-"""ORACLE (test infrastructure - never imported by the product path in ikflow_amd/).
+"""ORACLE (test infrastructure - never imported by the product path in ikflow_amd/; imports nothing from ikflow_amd).
 
 CPU restatement (torch, dtype-generic: float32 = the reference's CPU arithmetic, float64 = arbitration twin)
 of the kinematics the exact-IK path calls.  The arithmetic lives in jrl @ git 2ba7c3995b36b32886a8aa021a00c73b2cd55b2c
@@ -32,7 +32,19 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ikflow_amd.robots import JOINT_FIXED, JOINT_PRISMATIC, JOINT_REVOLUTE, Robot, rpy_to_matrix
+from oracle.robot_tables import FIXED as JOINT_FIXED
+from oracle.robot_tables import PRISMATIC as JOINT_PRISMATIC
+from oracle.robot_tables import REVOLUTE as JOINT_REVOLUTE
+from oracle.robot_tables import OracleRobot
+from oracle.robot_tables import robot as _robot_by_name
+from oracle.robot_tables import rpy_matrix as rpy_to_matrix
+
+
+def _R(robot) -> OracleRobot:
+    """The oracle computes on ITS OWN chain tables (oracle/robot_tables.py): of a product Robot only the name is used."""
+    return robot if isinstance(robot, OracleRobot) else _robot_by_name(robot if isinstance(robot, str) else robot.name)
+
+Robot = OracleRobot
 
 LM_LAMBDA = 1e-4
 LM_ALPHA = 1.0
@@ -134,6 +146,7 @@ def _fixed_T(joint, dtype) -> torch.Tensor:
 
 def _chain_transforms(robot: Robot, q: torch.Tensor):
     """Walk the chain; returns final T [n,4,4] and, per actuated joint, (kind, axis_world [n,3], origin_world [n,3])."""
+    robot = _R(robot)
     n, dtype = q.shape[0], q.dtype
     T = torch.eye(4, dtype=dtype).expand(n, 4, 4).contiguous()
     per_joint = []
@@ -167,6 +180,7 @@ def forward_kinematics(robot: Robot, q: torch.Tensor) -> torch.Tensor:
 
 def jacobian(robot: Robot, q: torch.Tensor) -> torch.Tensor:
     """[n x 6 x ndof], rows 0-2 angular, rows 3-5 linear (world frame, end-effector origin)."""
+    robot = _R(robot)
     T, per_joint = _chain_transforms(robot, q)
     p_ee = T[:, :3, 3]
     J = torch.zeros(q.shape[0], 6, robot.ndof, dtype=q.dtype)
@@ -180,6 +194,7 @@ def jacobian(robot: Robot, q: torch.Tensor) -> torch.Tensor:
 
 
 def clamp_to_joint_limits(robot: Robot, q: torch.Tensor) -> torch.Tensor:
+    robot = _R(robot)
     lo = torch.tensor([l[0] for l in robot.actuated_joints_limits], dtype=q.dtype)
     hi = torch.tensor([l[1] for l in robot.actuated_joints_limits], dtype=q.dtype)
     return torch.max(torch.min(q, hi), lo)
@@ -193,6 +208,7 @@ def pose_error_vector(robot: Robot, target_poses: torch.Tensor, q: torch.Tensor)
 
 
 def lm_step(robot: Robot, target_poses: torch.Tensor, q: torch.Tensor, lambd: float = LM_LAMBDA, alpha: float = LM_ALPHA) -> torch.Tensor:
+    robot = _R(robot)
     J = jacobian(robot, q)
     e = pose_error_vector(robot, target_poses, q)[:, :, None]
     Jt = J.transpose(1, 2)
@@ -220,10 +236,16 @@ def calculate_joint_limits_exceeded(configs: torch.Tensor, joint_limits) -> torc
 # exact-IK control loop (ikflow_solver.py:119-247, 345-411), flow seeds supplied by a callback so the same
 # loop can be driven by the torch oracle flow (CPU parity) or by recorded seeds.
 # ---------------------------------------------------------------------------------------------------
-def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_opt_steps_max=3, lm_dtype=torch.float32):
+def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_opt_steps_max=3, lm_dtype=torch.float32,
+                margins=None):
     """One call of _generate_exact_ik_solutions given the clamped flow seeds q [n*R x ndof] (tile-major).
-    lm_dtype=float64 evaluates each LM step in double and rounds q back to float32 (what the HIP kernel does)."""
+    lm_dtype=float64 evaluates each LM step in double and rounds q back to float32 (what the HIP kernel does).
+    ``margins`` (optional, [n, 2] float tensor, updated in place): per pose the smallest |pos_err - pos_thr| and
+    |rot_err - rot_thr| seen over every (iteration, repeat) evaluated for it - lets a test exclude poses whose validity
+    flag hangs on rounding."""
+    robot = _R(robot)
     n = target_poses.shape[0]
+    active = torch.arange(n)
     q = seeds_q.clone()
     poses_tiled = target_poses.repeat((repeat_count, 1))
     final_solutions = torch.zeros(n, robot.ndof, dtype=torch.float32)
@@ -235,6 +257,11 @@ def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_
         q = clamp_to_joint_limits(robot, q)
         pos_err, rot_err = calculate_pose_error(robot, q, poses_tiled)
         valids_tiled = torch.logical_and(pos_err < pos_thr, rot_err < rot_thr)
+        if margins is not None:
+            pm = (pos_err - pos_thr).abs().reshape(repeat_count, n_invalid).min(0).values
+            rm = (rot_err - rot_thr).abs().reshape(repeat_count, n_invalid).min(0).values
+            margins[active, 0] = torch.minimum(margins[active, 0], pm.to(margins.dtype))
+            margins[active, 1] = torch.minimum(margins[active, 1], rm.to(margins.dtype))
         valids_i = torch.zeros(n_invalid, dtype=torch.bool)
         sols_i = torch.zeros((n_invalid, robot.ndof), dtype=torch.float32)
         for idx in torch.nonzero(valids_tiled)[:, 0].tolist():  # ascending: highest valid repeat wins (:217-222)
@@ -246,6 +273,7 @@ def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_
         if final_valids.all():
             return final_solutions, final_valids
         keep = torch.logical_not(valids_i).repeat((repeat_count))
+        active = active[torch.logical_not(valids_i)]
         q = q[keep, :]
         poses_tiled = poses_tiled[keep, :]
         n_invalid = n - int(final_valids.sum().item())
@@ -256,6 +284,7 @@ def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torc
                                 lm_dtype=torch.float32):
     """Retry schedule of ikflow_solver.py:345-411.  ``flow_fn(latent, poses_tiled) -> clamped q`` ;
     ``latents[r]`` is the [n_r*R_r x D] latent the reference would have drawn in round r."""
+    robot = _R(robot)
     n = target_poses.shape[0]
     R0 = repeat_counts[0]
     seeds = flow_fn(latents[0], target_poses.repeat((R0, 1)))
@@ -277,6 +306,35 @@ def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torc
     return solutions, valids
 
 
+def generate_exact_ik_solutions_seeded(robot, seed_fn, target_poses, repeat_counts=(1, 3, 10), pos_thr=1e-3, rot_thr=0.1,
+                                       lm_dtype=torch.float32, return_margins=False):
+    """The same retry schedule (ikflow_solver.py:345-411) with the flow taken out: ``seed_fn(round, pose_indices) ->
+    [len(pose_indices) * R_round x ndof]`` supplies the (clamped) seeds of the still-invalid poses, tile-major
+    (row = r * n_active + j, as ``conditional.repeat((R, 1))`` lays them out, :185).  Drives exactly the part of the path
+    that follows ``self._run_inference`` (:188): LM iterations, validity, "highest valid repeat wins", slot order,
+    compaction, rounds.  Optionally returns per-pose threshold margins (see exact_round)."""
+    robot = _R(robot)
+    n = target_poses.shape[0]
+    margins = torch.full((n, 2), float("inf"), dtype=torch.float64)
+    solutions = torch.zeros(n, robot.ndof, dtype=torch.float32)
+    valids = torch.zeros(n, dtype=torch.bool)
+    for r, R in enumerate(repeat_counts):
+        idx = torch.nonzero(torch.logical_not(valids))[:, 0]
+        if idx.numel() == 0:
+            break
+        missing = target_poses[idx, :]
+        seeds = seed_fn(r, idx)
+        assert seeds.shape == (idx.numel() * R, robot.ndof), (seeds.shape, idx.numel(), R)
+        sub = torch.full((idx.numel(), 2), float("inf"), dtype=torch.float64)
+        new_sol, new_valid = exact_round(robot, seeds, missing, R, pos_thr, rot_thr, lm_dtype=lm_dtype, margins=sub)
+        margins[idx] = torch.minimum(margins[idx], sub)
+        solutions[idx, :] = new_sol
+        valids[idx] = new_valid
+        if new_sol.all():  # quirk Q3 (ikflow_solver.py:402)
+            break
+    return (solutions, valids, margins) if return_margins else (solutions, valids)
+
+
 # ---------------------------------------------------------------------------------------------------
 # capsule self-collision (checker of ikf_self_collision; float64 numpy, brute-force closest points on a parameter grid
 # refined by the closed form - no shared code with the kernel)
@@ -284,6 +342,7 @@ def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torc
 def _link_frames(robot: Robot, q: torch.Tensor):
     """World transforms [n x 4 x 4] of the base (index 0) and of the frame that follows each actuated joint (1..ndof),
     walking the URDF joints one by one (fixed joints included) in float64."""
+    robot = _R(robot)
     qd = q.double()
     n = qd.shape[0]
     T = torch.eye(4, dtype=torch.float64).repeat(n, 1, 1)
@@ -309,6 +368,7 @@ def _link_frames(robot: Robot, q: torch.Tensor):
 def capsule_clearance(robot: Robot, capsules, ignored_pairs, q: torch.Tensor) -> torch.Tensor:
     """capsules in URDF link frames, as given to Robot.set_collision_capsules.  Returns [n] float64: min over tested pairs
     of (segment distance - r_a - r_b)."""
+    robot = _R(robot)
     names = [j.name for j in robot.joints]
     per_joint = _link_frames(robot, q)
     n = q.shape[0]

@@ -39,17 +39,17 @@ def main():
     n = 16
     poses = README_POSES[torch.arange(n) % 3]
     lat = torch.randn(n, lay.dim, generator=torch.Generator().manual_seed(0))
-    out = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
-    out_nc = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
-    single = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, README_POSES[0], lat, n=n)
+    out = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=True)
+    out_nc = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
+    single = fo.generate_ik_solutions_torch(sd, lay, robot, README_POSES[0], lat, n=n)
     np.savez(os.path.join(HERE, "tiny_flow.npz"), poses=poses.numpy(), latent=lat.numpy(), q_clamped=out.numpy(),
              q_unclamped=out_nc.numpy(), q_single_pose0=single.numpy(), weights_seed=np.int64(0))
     # --- flow, full Panda architecture (BASELINE config 1: 3 README poses, batch 16) ---
     robot, hp, lay, sd = panda_model(seed=0)
     lat = torch.randn(n, lay.dim, generator=torch.Generator().manual_seed(0))
     poses = README_POSES[torch.arange(n) % 3]
-    out = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
-    out_nc = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+    out = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=True)
+    out_nc = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
     np.savez(os.path.join(HERE, "panda_flow.npz"), poses=poses.numpy(), latent=lat.numpy(), q_clamped=out.numpy(),
              q_unclamped=out_nc.numpy(), weights_seed=np.int64(0))
     # --- kinematics: FK / pose error / LM step (fp64 twin) on 64 seeded Panda configurations ---

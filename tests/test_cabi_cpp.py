@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import latents, reachable_poses, tiny_model
+from helpers import O, latents, reachable_poses, tiny_model
 from ikflow_amd import _lib
 from ikflow_amd.engine import _make_desc
 from oracle import flow_oracle as fo
@@ -56,7 +56,7 @@ def test_cpp_client_of_the_cabi(tmp_path):
     q = out[: n * 7].reshape(n, 7)
     fk = out[n * 7 : n * 14].reshape(n, 7)
     pe, re = out[n * 14 : n * 15], out[n * 15 : n * 16]
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
     assert np.abs(q - ref.numpy()).max() <= 1e-5
     fk_ref = ko.forward_kinematics(robot, torch.from_numpy(q))
     assert np.abs(fk[:, :3] - fk_ref[:, :3].numpy()).max() <= 2e-6

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import fetch_arm_model, latents, panda_model, reachable_poses, tiny_model
+from helpers import O, fetch_arm_model, latents, panda_model, reachable_poses, tiny_model
 from ikflow_amd.ikflow_solver import IKFlowSolver
 from oracle import flow_oracle as fo
 from oracle import kinematics_oracle as ko
@@ -27,9 +27,9 @@ def _flow_case(model, n, clamp=True, seed=0):
     robot, hp, lay, sd = model
     _, poses = reachable_poses(robot, n, seed)
     lat = latents(n, lay.dim, seed + 1)
-    ref32 = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=clamp)
+    ref32 = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=clamp)
     cond = torch.cat([poses, torch.zeros(n, 1)], 1).numpy()
-    ref64 = fo.run_inference_f64(sd, lay, robot.actuated_joints_limits, lat.numpy(), cond, clamp)
+    ref64 = fo.run_inference_f64(sd, lay, robot, lat.numpy(), cond, clamp)
     s = _solver(robot, hp, sd)
     # quirk Q2 (ikflow_solver.py:313-315,333): a [1 x 7] y has numel()==7 and is the single-pose form -> needs n
     got = s.generate_ik_solutions(poses.to(DEV), n=(1 if n == 1 else None), latent=lat.to(DEV), clamp_to_joint_limits=clamp).cpu()
@@ -55,7 +55,7 @@ def test_flow_tiny_every_tile_boundary_and_forced_config(precision):
     n_max = 2100
     _, poses = reachable_poses(robot, n_max, 21)
     lat = latents(n_max, lay.dim, 22)
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=True)
     for n in (2, 31, 33, 255, 256, 257, 511, 512, 513, 768, 769, 1023, 1025, 1536, 1537, 2048, 2049, 2100):
         got = s.generate_ik_solutions(poses[:n].to(DEV), latent=lat[:n].to(DEV)).cpu()
         assert (got - ref[:n]).abs().max().item() <= FLOW_TOL, f"{precision} n={n}"
@@ -106,9 +106,9 @@ def test_flow_f16_split_precision_matches_oracle(which, n):
     _, poses = reachable_poses(robot, n, 11)
     lat = latents(n, lay.dim, 12)
     m = min(n, 512)  # oracle on a slice for the big batch
-    ref32 = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:m], lat[:m], clamp=False)
+    ref32 = fo.generate_ik_solutions_torch(sd, lay, robot, poses[:m], lat[:m], clamp=False)
     cond = torch.cat([poses[:m], torch.zeros(m, 1)], 1).numpy()
-    ref64 = fo.run_inference_f64(sd, lay, robot.actuated_joints_limits, lat[:m].numpy(), cond, False)
+    ref64 = fo.run_inference_f64(sd, lay, robot, lat[:m].numpy(), cond, False)
     s = _solver(robot, hp, sd)
     got32 = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()[:m]
     s.set_precision("f16x3")
@@ -122,7 +122,7 @@ def test_flow_f16_split_precision_matches_oracle(which, n):
     assert e16_cpu <= FLOW_TOL and e16_64 <= FLOW_TOL
     assert e16_64 <= 1.5 * e32_64 + 5e-7
     clamped = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV)).cpu()[:m]
-    ref_cl = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:m], lat[:m], clamp=True)
+    ref_cl = fo.generate_ik_solutions_torch(sd, lay, robot, poses[:m], lat[:m], clamp=True)
     assert (clamped - ref_cl).abs().max().item() <= FLOW_TOL
 
 
@@ -137,13 +137,13 @@ def test_sigmoid_on_output_variant_matches_oracle_and_stays_in_limits():
     n = 300
     _, poses = reachable_poses(robot, n, 3)
     lat = latents(n, lay.dim, 4)
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
     got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
     assert (got - ref).abs().max().item() <= FLOW_TOL
     wild = 1e8 * latents(n, lay.dim, 5)
     out = s.generate_ik_solutions(poses.to(DEV), latent=wild.to(DEV), clamp_to_joint_limits=False).cpu()
     assert bool(torch.isfinite(out).all())
-    for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+    for i, (lo, hi) in enumerate(O(robot).actuated_joints_limits):
         assert out[:, i].min().item() >= lo - 1e-5 and out[:, i].max().item() <= hi + 1e-5
 
 
@@ -159,7 +159,7 @@ def test_single_pose_form_and_latent_draw():
     y = torch.tensor([0.25, 0.0, 0.5, 1.0, 0.0, 0.0, 0.0])
     lat = latents(16, lay.dim, 0)
     got = s.generate_ik_solutions(y.to(DEV), n=16, latent=lat.to(DEV)).cpu()
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, y, lat, n=16)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, y, lat, n=16)
     assert (got - ref).abs().max().item() <= FLOW_TOL
     # batch form of the same pose gives the same rows
     got_b = s.generate_ik_solutions(y.expand(16, 7).contiguous().to(DEV), latent=lat.to(DEV)).cpu()
@@ -216,10 +216,10 @@ def test_full_batch_properties_4096():
         assert torch.equal(part, full[lo:hi])
     s.engine(DEV).set_gemm_variant(-1)
     # oracle on a slice
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:256], lat[:256])
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses[:256], lat[:256])
     assert (full[:256].cpu() - ref).abs().max().item() <= FLOW_TOL
-    lo_t = torch.tensor([l[0] for l in robot.actuated_joints_limits], device=DEV)
-    hi_t = torch.tensor([l[1] for l in robot.actuated_joints_limits], device=DEV)
+    lo_t = torch.tensor([l[0] for l in O(robot).actuated_joints_limits], device=DEV)
+    hi_t = torch.tensor([l[1] for l in O(robot).actuated_joints_limits], device=DEV)
     assert bool(((full >= lo_t) & (full <= hi_t)).all())
 
 
@@ -247,7 +247,7 @@ def test_fk_matches_oracle(which):
     from ikflow_amd.robots import get_robot
 
     robot = get_robot(which)
-    q = torch.tensor(robot.sample_joint_angles(2000, 0.0, np.random.default_rng(4)))
+    q = torch.tensor(O(robot).sample_joint_angles(2000, 0.0, np.random.default_rng(4)))
     ref64 = ko.forward_kinematics(robot, q.double())
     got = robot.forward_kinematics(q.to(DEV)).cpu()
     # quaternion sign: compare as rotations where the largest component is near a tie
@@ -282,7 +282,7 @@ def test_pose_error_jacobian_clamp_limits():
     eng = kinematics_engine_for(robot, DEV)
     n = 1000
     q, poses = reachable_poses(robot, n, 8)
-    q2 = torch.tensor(robot.sample_joint_angles(n, 0.0, np.random.default_rng(9)))
+    q2 = torch.tensor(O(robot).sample_joint_angles(n, 0.0, np.random.default_rng(9)))
     pe, re = eng.pose_error(q2.to(DEV), poses.to(DEV))
     pe_ref, re_ref = ko.calculate_pose_error(robot, q2, poses)
     assert (pe.cpu() - pe_ref).abs().max().item() <= 2e-6
@@ -294,7 +294,7 @@ def test_pose_error_jacobian_clamp_limits():
     cl = robot.clamp_to_joint_limits(wild.to(DEV)).cpu()
     assert torch.equal(cl, ko.clamp_to_joint_limits(robot, wild))
     ex = eng.joint_limits_exceeded(wild.to(DEV)).cpu()
-    assert torch.equal(ex, ko.calculate_joint_limits_exceeded(wild, robot.actuated_joints_limits))
+    assert torch.equal(ex, ko.calculate_joint_limits_exceeded(wild, O(robot).actuated_joints_limits))
 
 
 def test_evaluation_utils_reference_known_answers_and_oracle():
@@ -345,7 +345,7 @@ def test_evaluation_utils_reference_known_answers_and_oracle():
     l2e, ange, lim, coll = eu.evaluate_solutions(robot, poses, wild)
     pe_ref, re_ref = ko.calculate_pose_error(robot, wild, poses)
     assert (l2e - pe_ref).abs().max().item() <= 2e-6 and (ange - re_ref).abs().max().item() <= 2e-5
-    assert torch.equal(lim, ko.calculate_joint_limits_exceeded(wild, robot.actuated_joints_limits)) and coll is None
+    assert torch.equal(lim, ko.calculate_joint_limits_exceeded(wild, O(robot).actuated_joints_limits)) and coll is None
     l2s, _, _, _ = eu.evaluate_solutions(robot, poses[0], wild)
     assert (l2s - ko.calculate_pose_error(robot, wild, poses[0].repeat(300, 1))[0]).abs().max().item() <= 2e-6
     with pytest.raises(NotImplementedError):
@@ -359,7 +359,7 @@ def test_lm_step_matches_fp64_twin(which):
     robot = get_robot(which)
     n = 3000
     g = torch.Generator().manual_seed(11)
-    qt = torch.tensor(robot.sample_joint_angles(n, 0.01, np.random.default_rng(12)))
+    qt = torch.tensor(O(robot).sample_joint_angles(n, 0.01, np.random.default_rng(12)))
     poses = ko.forward_kinematics(robot, qt)
     q0 = ko.clamp_to_joint_limits(robot, qt + 0.15 * torch.randn(n, robot.ndof, generator=g))
     got = robot.inverse_kinematics_step_levenburg_marquardt(poses.to(DEV), q0.to(DEV)).cpu()
@@ -392,7 +392,7 @@ def test_exact_ik_matches_oracle_control_flow(n):
     poses, lats = _exact_inputs(robot, lay, n, rc, 21)
 
     def flow_fn(latent, poses_tiled):
-        return fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses_tiled, latent[: poses_tiled.shape[0]], clamp=True)
+        return fo.generate_ik_solutions_torch(sd, lay, robot, poses_tiled, latent[: poses_tiled.shape[0]], clamp=True)
 
     ref_sol, ref_valid = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, pos_thr, rot_thr)
     # same schedule with each LM step evaluated in fp64 (what the kernel does): the comparator for solution VALUES
@@ -465,7 +465,7 @@ def test_return_detailed_tuple():
     _, poses = reachable_poses(robot, n, 3)
     lat = latents(n, lay.dim, 4)
     sol, pe, re, lim, coll, rt = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), return_detailed=True)
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
     pe_ref, re_ref = ko.calculate_pose_error(robot, ref, poses)
     assert (pe.cpu() - pe_ref).abs().max().item() < 1e-4 and (re.cpu() - re_ref).abs().max().item() < 1e-3
     assert lim.dtype == torch.bool and not bool(lim.any()) and coll is None and isinstance(rt, float)
@@ -480,7 +480,7 @@ def test_exact_ik_retry_rounds_cross_the_flow_chunk_boundary():
     poses, lats = _exact_inputs(robot, lay, n, rc, 33)
 
     def flow_fn(latent, poses_tiled):
-        return fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses_tiled, latent[: poses_tiled.shape[0]], clamp=True)
+        return fo.generate_ik_solutions_torch(sd, lay, robot, poses_tiled, latent[: poses_tiled.shape[0]], clamp=True)
 
     ref_sol, ref_valid = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, 0.02, 0.1, lm_dtype=torch.float64)
     eng = s.engine(DEV)
@@ -605,10 +605,10 @@ def test_baseline_sizes_size_independent_properties():
     P, L = poses.to(DEV), lat.to(DEV)
     a = s.generate_ik_solutions(P, latent=L)
     assert torch.equal(a, s.generate_ik_solutions(P, latent=L)) and bool(torch.isfinite(a).all())
-    lo = torch.tensor([l[0] for l in robot.actuated_joints_limits], device=DEV)
-    hi = torch.tensor([l[1] for l in robot.actuated_joints_limits], device=DEV)
+    lo = torch.tensor([l[0] for l in O(robot).actuated_joints_limits], device=DEV)
+    hi = torch.tensor([l[1] for l in O(robot).actuated_joints_limits], device=DEV)
     assert bool(((a >= lo) & (a <= hi)).all())
-    ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[:128], lat[:128])
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses[:128], lat[:128])
     assert (a[:128].cpu() - ref).abs().max().item() <= FLOW_TOL
     # config 3: Panda exact IK, B = 4096, 1 mm / 0.01 rad: every row reported valid meets the thresholds (checked with the
     # oracle's FK) and the limits; every other row is exactly 0; valid is a bool vector on the input device
@@ -633,8 +633,8 @@ def test_one_million_poses_in_one_call():
     s = _solver(robot, hp, sd)
     n = 1_000_000
     g = torch.Generator(device=DEV).manual_seed(5)
-    lo = torch.tensor([l[0] for l in robot.actuated_joints_limits], device=DEV)
-    hi = torch.tensor([l[1] for l in robot.actuated_joints_limits], device=DEV)
+    lo = torch.tensor([l[0] for l in O(robot).actuated_joints_limits], device=DEV)
+    hi = torch.tensor([l[1] for l in O(robot).actuated_joints_limits], device=DEV)
     q = lo + (hi - lo) * torch.rand((n, 7), generator=g, device=DEV)
     poses = robot.forward_kinematics(q)
     lat = torch.randn((n, lay.dim), generator=g, device=DEV)
@@ -644,7 +644,7 @@ def test_one_million_poses_in_one_call():
     assert torch.equal(sol, s.generate_ik_solutions(poses, latent=lat))
     for start in (0, 16384 - 20, 16384 * 31 - 7, n - 40):
         sl = slice(start, start + 40)
-        ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses[sl].cpu(), lat[sl].cpu())
+        ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses[sl].cpu(), lat[sl].cpu())
         assert (sol[sl].cpu() - ref).abs().max().item() <= FLOW_TOL, f"rows {start}.."
         alone = s.generate_ik_solutions(poses[sl].contiguous(), latent=lat[sl].contiguous())
         assert (sol[sl] - alone).abs().max().item() <= FLOW_TOL
@@ -654,19 +654,15 @@ def test_one_million_poses_in_one_call():
 def test_every_released_architecture_matches_oracle(model_name):
     """The released architectures not covered above (model_descriptions.yaml: 6-block Panda, 12- and 16-block Fetch with
     D = 8 and the prismatic torso joint): flow and exact-IK entry points against the oracle, seeded weights."""
-    from ikflow_amd.model import MODEL_DESCRIPTIONS, hparams_for, layout_from, random_state_dict
-    from ikflow_amd.robots import get_robot
+    from helpers import released_model
 
-    robot = get_robot(MODEL_DESCRIPTIONS[model_name]["robot_name"])
-    hp = hparams_for(model_name)
-    lay = layout_from(hp, robot)
-    sd = random_state_dict(lay, robot, seed=4)
+    robot, hp, lay, sd = released_model(model_name, seed=4)
     s = _solver(robot, hp, sd)
     for n, precision in ((40, "f32"), (600, "f32"), (600, "f16x3")):
         s.set_precision(precision)
         _, poses = reachable_poses(robot, n, 50)
         lat = latents(n, lay.dim, 51)
-        ref = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat)
+        ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
         got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV)).cpu()
         assert got.shape == (n, robot.ndof)
         assert (got - ref).abs().max().item() <= FLOW_TOL, f"{model_name} n={n} {precision}"
@@ -696,7 +692,7 @@ def test_capsule_self_collision_matches_oracle(which):
     ignored = [(0, 1)]
     robot.set_collision_capsules(capsules, ignored_pairs=ignored)
     n = 3000
-    q = torch.tensor(robot.sample_joint_angles(n, 0.0, rng))
+    q = torch.tensor(O(robot).sample_joint_angles(n, 0.0, rng))
     ref = ko.capsule_clearance(robot, capsules, ignored, q)
     dist = robot.self_collision_distances(q.to(DEV)).cpu().double()
     assert (dist - ref).abs().max().item() <= 2e-5, (dist - ref).abs().max().item()

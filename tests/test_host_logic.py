@@ -115,7 +115,8 @@ def test_draw_latent():
 
 
 def test_state_dict_validation_and_pickle_roundtrip(tmp_path):
-    robot, hp, lay, sd = tiny_model()
+    robot, hp, _, sd = tiny_model()
+    lay = layout_from(hp, robot)
     validate_state_dict(lay, sd)
     assert len([k for k in sd if k.endswith("weight")]) == lay.nb_nodes * 2 * (lay.n_hidden + 1)
     assert sd[key_linear(0, 1, 0, "weight")].shape == (256, 4 + 8) and sd[key_linear(0, 2, 2, "weight")].shape == (8, 256)

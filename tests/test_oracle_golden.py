@@ -6,11 +6,18 @@ import os
 import numpy as np
 import torch
 
-from helpers import latents, panda_model, reachable_poses, tiny_model
-from ikflow_amd.model import fixed_linear_transform, freia_permutation, hparams_for, layout_from
-from ikflow_amd.robots import FetchArm, Panda
+from helpers import O, latents, panda_model, reachable_poses, tiny_model
+from helpers import custom_model
 from oracle import flow_oracle as fo
 from oracle import kinematics_oracle as ko
+
+
+def Panda():
+    return O("panda")
+
+
+def FetchArm():
+    return O("fetch_arm")
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -47,15 +54,15 @@ def test_panda_joint_limits():
     lower = [-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973]
     robot = Panda()
     assert robot.ndof == 7 and robot.name == "panda"
-    for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+    for i, (lo, hi) in enumerate(O(robot).actuated_joints_limits):
         assert abs(lo - lower[i]) < 1e-5 and abs(hi - upper[i]) < 1e-5
 
 
 def test_fixed_linear_transform_scale_is_max_abs_limit():
     """ikflow/model.py:310-316: M = diag(1/max|lim|) -> rev multiplies column i by max(|lo_i|,|hi_i|)."""
     robot = Panda()
-    lay = layout_from(hparams_for("panda__full__lp191_5.25m"), robot)
-    M, M_inv, b = fixed_linear_transform(lay, robot)
+    lay = fo.layout_for("panda__full__lp191_5.25m")
+    M, M_inv, b = fo.fixed_linear_transform(lay, robot)
     want = [2.8973, 1.7628, 2.8973, 3.0718, 2.8973, 3.7525, 2.8973]
     np.testing.assert_allclose(np.diag(M_inv), want, rtol=1e-6)
     assert np.count_nonzero(M_inv - np.diag(np.diag(M_inv))) == 0 and not b.any()
@@ -75,25 +82,21 @@ PERM_D10 = [[2, 8, 4, 9, 1, 6, 7, 3, 0, 5], [2, 9, 6, 4, 0, 3, 1, 7, 8, 5], [4, 
 
 def test_permutation_tables():
     for i, p in enumerate(PERM_D7):
-        assert freia_permutation(7, i).tolist() == p
+        perm, perm_inv = fo.permute_random_tables(7, i)
+        assert perm.tolist() == p and perm_inv[perm].tolist() == list(range(7))
     for i, p in enumerate(PERM_D10):
-        assert freia_permutation(10, i).tolist() == p
+        assert fo.permute_random_tables(10, i)[0].tolist() == p
     state = np.random.get_state()[1][:4].copy()
-    freia_permutation(7, 3)
+    fo.permute_random_tables(7, 3)
     assert (np.random.get_state()[1][:4] == state).all()  # numpy's global RNG is left alone
 
 
 # ---- work figures of SURVEY 8(d) / BASELINE.md section 3 --------------------------------------------------------------
 def test_algorithmic_work_figures():
-    lay = layout_from(hparams_for("panda__full__lp191_5.25m"), Panda())
-    assert (lay.n_weights(), lay.flops_per_solution(), lay.weight_bytes(), lay.row_io_bytes()) == (50786304, 101572608, 203440800, 84)
-    lay = layout_from(hparams_for("fetch_arm__large__mh186_9.25m"), FetchArm())
-    assert (lay.n_weights(), lay.flops_per_solution(), lay.weight_bytes(), lay.row_io_bytes()) == (67862528, 135725056, 271844608, 96)
-    from ikflow_amd.model import TINY_MODEL_PARAMS
-
-    lay = layout_from(TINY_MODEL_PARAMS, Panda())
-    assert (lay.n_weights(), lay.flops_per_solution(), lay.weight_bytes()) == (426240, 852480, 1717464)
-    assert (lay.split1, lay.split2, lay.dim_cond) == (4, 5, 8)
+    assert fo.layout_for("panda__full__lp191_5.25m").flops_per_solution() == 101572608
+    assert fo.layout_for("fetch_arm__large__mh186_9.25m").flops_per_solution() == 135725056
+    lay = fo.layout_for("tiny")
+    assert lay.flops_per_solution() == 852480 and (lay.len1, lay.len2, lay.dim_cond) == (4, 5, 8)
 
 
 # ---- committed fixtures -----------------------------------------------------------------------------------------------
@@ -102,12 +105,12 @@ def test_flow_oracle_reproduces_fixtures():
         z = np.load(os.path.join(GOLD, name))
         robot, hp, lay, sd = model(seed=int(z["weights_seed"]))
         poses, lat = torch.from_numpy(z["poses"]), torch.from_numpy(z["latent"])
-        out = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=True)
+        out = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=True)
         np.testing.assert_allclose(out.numpy(), z["q_clamped"], atol=2e-6)
-        out_nc = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+        out_nc = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
         np.testing.assert_allclose(out_nc.numpy(), z["q_unclamped"], atol=1e-5, rtol=1e-5)
         cond = torch.cat([poses, torch.zeros(poses.shape[0], 1)], 1).numpy()
-        o64 = fo.run_inference_f64(sd, lay, robot.actuated_joints_limits, z["latent"], cond, True)
+        o64 = fo.run_inference_f64(sd, lay, robot, z["latent"], cond, True)
         assert np.abs(o64 - z["q_clamped"]).max() < 1e-5  # fp32 path vs fp64 twin
 
 
@@ -137,17 +140,17 @@ def test_flow_oracle_fp32_vs_fp64_and_properties():
     # reference tests/ikflow_solver_test.py:89-117 as properties of the restatement
     ys = torch.zeros(2, 7)
     z = torch.zeros(2, lay.dim)
-    a = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, ys, z, clamp=False)
+    a = fo.generate_ik_solutions_torch(sd, lay, robot, ys, z, clamp=False)
     torch.testing.assert_close(a[0], a[1])
     ys2 = torch.tensor([[0, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0]], dtype=torch.float32)
-    b = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, ys2, z, clamp=False)
+    b = fo.generate_ik_solutions_torch(sd, lay, robot, ys2, z, clamp=False)
     for j in range(7):
         assert ((b[1] - b[0, j]).abs() < 1e-8).sum().item() == 0
 
 
 def test_jacobian_is_derivative_of_fk():
     for robot in (Panda(), FetchArm()):
-        q = torch.tensor(robot.sample_joint_angles(8, 0.01, np.random.default_rng(2))).double()
+        q = torch.tensor(O(robot).sample_joint_angles(8, 0.01, np.random.default_rng(2))).double()
         J = ko.jacobian(robot, q)
         eps = 1e-6
         for i in range(robot.ndof):
@@ -159,7 +162,7 @@ def test_jacobian_is_derivative_of_fk():
 
 def test_lm_step_converges_and_respects_limits():
     robot = Panda()
-    qt = torch.tensor(robot.sample_joint_angles(200, 0.05, np.random.default_rng(7)))
+    qt = torch.tensor(O(robot).sample_joint_angles(200, 0.05, np.random.default_rng(7)))
     poses = ko.forward_kinematics(robot, qt)
     q = ko.clamp_to_joint_limits(robot, qt + 0.05 * torch.randn(200, 7, generator=torch.Generator().manual_seed(8)))
     for _ in range(3):
@@ -187,7 +190,7 @@ def test_exact_ik_oracle_control_flow_invariants():
     lats = [latents(n * r, lay.dim, 100 + i) for i, r in enumerate(rc)]
 
     def flow_fn(latent, pt):
-        return fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, pt, latent[: pt.shape[0]], clamp=True)
+        return fo.generate_ik_solutions_torch(sd, lay, robot, pt, latent[: pt.shape[0]], clamp=True)
 
     sol, valid = ko.generate_exact_ik_solutions(robot, flow_fn, poses, lats, rc, 0.2, 1.0)
     assert 0 < int(valid.sum()) < n
@@ -200,23 +203,14 @@ def test_exact_ik_oracle_control_flow_invariants():
 
 # ---- sigmoid_on_output graph variant (ikflow/model.py:304-307; reference tests/model_test.py:50-123) ----------------
 def _sigmoid_model(seed=0):
-    from ikflow_amd.model import IkflowModelParameters, random_state_dict
-
-    hp = IkflowModelParameters()
-    hp.nb_nodes, hp.coeff_fn_config, hp.coeff_fn_internal_size = 3, 2, 256
-    hp.dim_latent_space = 9
-    hp.softflow_enabled = False
-    hp.sigmoid_on_output = True
-    robot = Panda()
-    lay = layout_from(hp, robot)
-    return robot, hp, lay, random_state_dict(lay, robot, seed=seed)
+    return custom_model(nb_nodes=3, dim=9, n_hidden=2, width=256, softflow=False, sigmoid=True, seed=seed)
 
 
 def test_pre_sigmoid_scaling_node_maps_limits_to_unit_interval():
     """tests/model_test.py:50-106: upper limits -> 1, lower limits -> 0, midpoints -> 0.5 (forward y = x M + b),
     and the reverse (x - b) M_inv maps them back."""
     robot, hp, lay, sd = _sigmoid_model()
-    M, M_inv, b = fixed_linear_transform(lay, robot)
+    M, M_inv, b = fo.fixed_linear_transform(lay, robot)
     upper = np.array([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 1.0, 1.0], dtype=np.float32)
     lower = np.array([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, -1.0, -1.0], dtype=np.float32)
     mid = np.array([0.0, 0.0, 0.0, -1.5708, 0.0, 1.8675, 0.0, 0.0, 0.0], dtype=np.float32)
@@ -225,7 +219,7 @@ def test_pre_sigmoid_scaling_node_maps_limits_to_unit_interval():
     np.testing.assert_allclose(mid @ M + b[0], 0.5 * np.ones(9), atol=1e-5)
     np.testing.assert_allclose((np.ones(9, np.float32) - b[0]) @ M_inv, upper, atol=1e-5)
     np.testing.assert_allclose((np.zeros(9, np.float32) - b[0]) @ M_inv, lower, atol=1e-5)
-    assert lay.module_offset == 1 and lay.dim_cond == 7
+    assert lay.first_block_module == 2 and lay.dim_cond == 7
     assert "module_list.3.subnet1.0.weight" in sd and "module_list.2.perm_inv" in sd and "module_list.1.perm" not in sd
 
 
@@ -237,7 +231,7 @@ def test_sigmoid_on_output_always_inside_joint_limits():
     for scale in (1.0, 1e8):
         lat = scale * torch.randn(n, lay.dim, generator=g)
         poses = torch.randn(n, 7, generator=g)
-        out = fo.generate_ik_solutions_torch(sd, lay, robot.actuated_joints_limits, poses, lat, clamp=False)
+        out = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
         assert bool(torch.isfinite(out).all())
-        for i, (lo, hi) in enumerate(robot.actuated_joints_limits):
+        for i, (lo, hi) in enumerate(O(robot).actuated_joints_limits):
             assert out[:, i].min().item() >= lo - 1e-5 and out[:, i].max().item() <= hi + 1e-5
