@@ -9,7 +9,7 @@ import os
 
 from ikflow_amd import build as _build
 
-IKF_ABI_VERSION = 2
+IKF_ABI_VERSION = 3
 IKF_MAX_DOF = 8
 IKF_MAX_DIM = 16
 IKF_MAX_ROUNDS = 8
@@ -63,6 +63,7 @@ class ikf_tensor(C.Structure):
 
 
 LATENT_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int)
+SEED_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol include/ikflow_amd.h declares
 SIGNATURES = {
@@ -73,6 +74,7 @@ SIGNATURES = {
     "ikf_load_weights": (C.c_int, [C.c_void_p, C.POINTER(ikf_tensor), C.c_int]),
     "ikf_weights_loaded": (C.c_int, [C.c_void_p]),
     "ikf_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
+    "ikf_reserve_exact": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
     "ikf_generate_approx": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
@@ -94,12 +96,26 @@ SIGNATURES = {
             LATENT_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
         ],
     ),
+    "ikf_generate_exact_seeded": (
+        C.c_int,
+        [
+            C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_float, C.c_float,
+            SEED_FN, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p,
+        ],
+    ),
+    "ikf_refine_exact": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "ikf_time_gemm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "ikf_profile_begin": (C.c_int, [C.c_void_p]),
     "ikf_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_void_p]),
     "ikf_profile_event_overhead_ms": (C.c_double, [C.c_void_p]),
     "ikf_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "ikf_get_precision": (C.c_int, [C.c_void_p]),
+    "ikf_set_split_guard": (C.c_int, [C.c_void_p, C.c_int]),
+    "ikf_split_fallback_count": (C.c_int64, [C.c_void_p]),
+    "ikf_split_overflow_pending": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ikf_split_kernel_name": (C.c_char_p, []),
     "ikf_dominant_kernel_name": (C.c_char_p, []),
     "ikf_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
         for (int q = 0; q < 4; ++q) {
           hi[q] = (_Float16)acc[q];
           lo[q] = (_Float16)((acc[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
+          if (split_out_of_range(acc[q]) && e.split_flag) atomicOr(e.split_flag, 1);
         }
         char* rowp = reinterpret_cast<char*>(e.h_out) + (size_t)(m0 + r) * e.width * 4 + (size_t)(c4 >> 3) * 128 + (c4 & 7) * 8;
         *reinterpret_cast<half4*>(rowp) = hi;

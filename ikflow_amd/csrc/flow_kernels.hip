@@ -522,9 +522,10 @@ hipError_t launch_gemm_lrelu(int variant, const float* A, const float* W, const 
 
 // ---------------------------------------------------------------------------------------------------------------
 // last Linear + affine-coupling inverse (+ permutation, + final rescale/clamp)
-// one wave per row; lane l owns k = 4*(64*g + l) .. +3 of the hidden row; the OUT x width weights live in VGPRs
+// one wave per row; lane l owns k = 4*(64*g + l) .. +3 of the hidden row (the unfused pipeline: n_hidden == 1 and the
+// forced gemm variants 0..8 - the fused pipeline reduces the last Linear inside the last contraction instead)
 // ---------------------------------------------------------------------------------------------------------------
-template <int OUT, int G>
+template <int OUT>
 __global__ __launch_bounds__(256) void k_last_layer_coupling(const float* __restrict__ w_last,
                                                              const float* __restrict__ b_last,
                                                              const float* __restrict__ h, FlowDims d, CouplingArgs ca,
@@ -533,32 +534,27 @@ __global__ __launch_bounds__(256) void k_last_layer_coupling(const float* __rest
   const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
   const int width = d.width;
-
-  float4 w[OUT][G];
-#pragma unroll
-  for (int j = 0; j < OUT; ++j)
-#pragma unroll
-    for (int g = 0; g < G; ++g) w[j][g] = reinterpret_cast<const float4*>(w_last + (size_t)j * width)[g * 64 + lane];
+  const int G = width >> 8;  // 256 hidden units per pass of the wave (4 per lane)
 
   const int D = d.D, L1 = d.L1, L2 = d.L2;
   const int nl = (ca.which == 1) ? L2 : L1;  // number of (s,t) pairs this subnet emits
 
   for (long long row = wave0; row < rows; row += nwaves) {
-    float4 hv[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) hv[g] = reinterpret_cast<const float4*>(h + (size_t)row * width)[g * 64 + lane];
     float a[OUT];
 #pragma unroll
-    for (int j = 0; j < OUT; ++j) {
-      float sacc = 0.f;
+    for (int j = 0; j < OUT; ++j) a[j] = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const float4 hv = reinterpret_cast<const float4*>(h + (size_t)row * width)[g * 64 + lane];
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        sacc = fmaf(hv[g].x, w[j][g].x, sacc);
-        sacc = fmaf(hv[g].y, w[j][g].y, sacc);
-        sacc = fmaf(hv[g].z, w[j][g].z, sacc);
-        sacc = fmaf(hv[g].w, w[j][g].w, sacc);
+      for (int j = 0; j < OUT; ++j) {
+        const float4 w = reinterpret_cast<const float4*>(w_last + (size_t)j * width)[g * 64 + lane];  // L2-resident
+        float sacc = a[j];
+        sacc = fmaf(hv.x, w.x, sacc);
+        sacc = fmaf(hv.y, w.y, sacc);
+        sacc = fmaf(hv.z, w.z, sacc);
+        sacc = fmaf(hv.w, w.w, sacc);
+        a[j] = sacc;
       }
-      a[j] = sacc;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
@@ -617,23 +613,10 @@ __global__ __launch_bounds__(256) void k_last_layer_coupling(const float* __rest
 template <int OUT>
 static hipError_t launch_last_g(const SubnetWeights& w, const FlowDims& d, const float* h_in, const CouplingArgs& ca,
                                 long long rows, hipStream_t s) {
-  const int G = d.width / 256;
-  long long waves = (rows + 3) / 4;  // ~4 rows per wave amortises the weight-register fill
+  long long waves = (rows + 3) / 4;  // ~4 rows per wave
   if (waves < 1) waves = 1;
   const unsigned grid = (unsigned)((waves + 3) / 4);
-#define IKF_LAST_CASE(GG)                                                                                        \
-  case GG:                                                                                                       \
-    hipLaunchKernelGGL((k_last_layer_coupling<OUT, GG>), dim3(grid), dim3(256), 0, s, w.w_last, w.b_last, h_in, d, \
-                       ca, rows);                                                                                \
-    break;
-  switch (G) {
-    IKF_LAST_CASE(1)
-    IKF_LAST_CASE(2)
-    IKF_LAST_CASE(4)
-    default:
-      return hipErrorInvalidValue;
-  }
-#undef IKF_LAST_CASE
+  hipLaunchKernelGGL((k_last_layer_coupling<OUT>), dim3(grid), dim3(256), 0, s, w.w_last, w.b_last, h_in, d, ca, rows);
   return hipGetLastError();
 }
 
@@ -642,6 +625,7 @@ hipError_t launch_last_layer_coupling(const SubnetWeights& w, const FlowDims& d,
   if (rows <= 0) return hipSuccess;
   if (d.width % 256 != 0) return hipErrorInvalidValue;
   switch (w.n_out) {
+    case 2: return launch_last_g<2>(w, d, h_in, ca, rows, s);
     case 4: return launch_last_g<4>(w, d, h_in, ca, rows, s);
     case 6: return launch_last_g<6>(w, d, h_in, ca, rows, s);
     case 8: return launch_last_g<8>(w, d, h_in, ca, rows, s);

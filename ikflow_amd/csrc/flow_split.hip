@@ -252,6 +252,7 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
     __syncthreads();
     char* Cb = reinterpret_cast<char*>(g.C);
     constexpr int CH = BN / 8;  // 8-column chunks per row
+    bool range_bad = false;
     for (int idx = t; idx < BM * CH; idx += NT) {
       const int rl = idx / CH, ch = idx - rl * CH;
       const floatx4 v0 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8);
@@ -263,12 +264,14 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
         lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
         hi[4 + q] = (_Float16)v1[q];
         lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
+        range_bad = range_bad || split_out_of_range(v0[q]) || split_out_of_range(v1[q]);
       }
       const int col = n0 + ch * 8;  // global column of the chunk; block of 32 columns = one 128-B line
       char* p = Cb + (size_t)(m0 + rl) * N * 4 + (size_t)(col >> 5) * 128 + (col & 31) * 2;
       *reinterpret_cast<half8*>(p) = hi;
       *reinterpret_cast<half8*>(p + 64) = lo;
     }
+    if (range_bad && g.flag) atomicOr(g.flag, 1);
   } else {
     // last Linear restricted to this tile's columns, in exact f32 MFMA (identical to k_flow_gemm<true>): one slot per 64 columns
     float* Wl = smem + BM * LDT;
@@ -484,6 +487,7 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
     __syncthreads();
     char* Cb = reinterpret_cast<char*>(g.C);
     constexpr int CH = BN / 8;
+    bool range_bad = false;
     for (int idx = t; idx < BM * CH; idx += NT) {
       const int rl = idx / CH, ch = idx - rl * CH;
       const floatx4 v0 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8);
@@ -495,12 +499,14 @@ __global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
         lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
         hi[4 + q] = (_Float16)v1[q];
         lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
+        range_bad = range_bad || split_out_of_range(v0[q]) || split_out_of_range(v1[q]);
       }
       const int col = n0 + ch * 8;
       char* p = Cb + (size_t)(m0 + rl) * N * 4 + (size_t)(col >> 5) * 128 + (col & 31) * 2;
       *reinterpret_cast<half8*>(p) = hi;
       *reinterpret_cast<half8*>(p + 64) = lo;
     }
+    if (range_bad && g.flag) atomicOr(g.flag, 1);
   } else {
     float* Wl = smem + BM * LDT;
     for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
@@ -696,6 +702,7 @@ __global__ __launch_bounds__(NH * SKKS * 64) void k_split_skinny(SplitGemmArgs g
       *reinterpret_cast<_Float16*>(p) = hi;
       *reinterpret_cast<_Float16*>(p + 64) = lo;
     }
+    if ((split_out_of_range(fin[0]) || split_out_of_range(fin[1])) && g.flag) atomicOr(g.flag, 1);
   } else {
     float* T = smem + KS * NH * 16 * 64;  // behind red[] (other waves may still be summing)
     float* Wl = T + BM * LDT;
@@ -825,7 +832,7 @@ hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipS
 
 // device: fp32 [rows][K] -> split-32 image; one thread converts 8 consecutive k of a row
 __global__ __launch_bounds__(256) void k_split32_pack(const float* __restrict__ src, long long n_chunks, int K,
-                                                      char* __restrict__ dst) {
+                                                      char* __restrict__ dst, int* __restrict__ flag) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_chunks) return;
   const int cpr = K / 8;  // chunks per row
@@ -840,18 +847,19 @@ __global__ __launch_bounds__(256) void k_split32_pack(const float* __restrict__ 
     lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
     hi[4 + q] = (_Float16)v1[q];
     lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
+    if ((split_out_of_range(v0[q]) || split_out_of_range(v1[q])) && flag) atomicOr(flag, 1);
   }
   char* p = dst + row * (long long)K * 4 + (long long)(k0 >> 5) * 128 + (k0 & 31) * 2;
   *reinterpret_cast<half8*>(p) = hi;
   *reinterpret_cast<half8*>(p + 64) = lo;
 }
 
-hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, hipStream_t s) {
+hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, int* d_flag, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   if (K % 32 != 0) return hipErrorInvalidValue;
   const long long n_chunks = rows * (K / 8);
   hipLaunchKernelGGL(k_split32_pack, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, d_src, n_chunks, K,
-                     reinterpret_cast<char*>(d_dst));
+                     reinterpret_cast<char*>(d_dst), d_flag);
   return hipGetLastError();
 }
 

@@ -26,8 +26,33 @@ static ikf_status fail(ikf_status code, const std::string& msg) {
                                    std::to_string(__LINE__) + ")");                                            \
   } while (0)
 
+// Every entry point runs on the handle's device and leaves the caller's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int device) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+    else if (err == hipSuccess) prev = -1;  // nothing to restore
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define IKF_ON_DEVICE(m)                                                                                       \
+  DeviceGuard dev_guard_((m)->device);                                                                         \
+  if (dev_guard_.err != hipSuccess)                                                                            \
+    return fail(IKF_ERR_HIP, std::string("hipSetDevice failed: ") + hipGetErrorString(dev_guard_.err));
+
 struct ikf_model {
   int device = 0;
+  // the per-handle scratch is shared by all calls: a call that arrives on a different stream than the previous one
+  // first waits for the event recorded behind the previous call's work
+  hipEvent_t tail_event = nullptr;
+  hipStream_t tail_stream = nullptr;
+  bool tail_valid = false;
   ikf_model_desc desc{};
   FlowDims dims{};
   bool loaded = false;
@@ -64,8 +89,14 @@ struct ikf_model {
   uint8_t* ex_row_valid = nullptr;  // [rows]
   int* ex_pose_idx = nullptr;     // [poses]
   uint8_t* ex_solved = nullptr;   // [poses]
+  int* ex_block_scratch = nullptr;  // [2 * compact_blocks(poses)] per-block counts / offsets of the ordered compaction
   int* ex_count = nullptr;        // device
   int* h_count = nullptr;         // pinned host
+  // f16x3 range guard
+  int* d_split_flag = nullptr;    // device word OR'ed by every kernel that produces a split operand out of the f16 range
+  int* h_split_flag = nullptr;    // pinned host
+  int split_guard = 1;
+  long long split_fallbacks = 0;
 
   // optional per-launch HIP-event timing of the dominant kernel (ikf_profile_begin/_end)
   bool prof_on = false;
@@ -86,7 +117,27 @@ static hipError_t prof_mark(ikf_model* m, hipStream_t s) {
   return hipEventRecord(m->prof_ev[m->prof_used++], s);
 }
 
-static const long long kMaxChunkRows = 16384;  // keeps the [chunk x width] activations (64 MB each) inside the 256 MB L3
+static hipError_t stream_enter(ikf_model* m, hipStream_t s) {
+  if (m->tail_valid && s != m->tail_stream) return hipStreamWaitEvent(s, m->tail_event, 0);
+  return hipSuccess;
+}
+static hipError_t stream_leave(ikf_model* m, hipStream_t s) {
+  if (!m->tail_event) {
+    hipError_t e = hipEventCreateWithFlags(&m->tail_event, hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+  }
+  m->tail_stream = s;
+  m->tail_valid = true;
+  return hipEventRecord(m->tail_event, s);
+}
+
+static const long long kMaxChunkRows = 16384;  // keeps the [chunk x width] activations (64 MB each at width 1024) inside the 256 MB L3
+// The kernels tile the hidden width in units of 256.  Any other coeff_fn_internal_size (ikflow/model.py:51-96 accepts any)
+// is run at the next multiple of 256 with zero weights and biases in the padding: a padded unit outputs lrelu(0) = 0 and
+// feeds 0 * 0 into every later sum, so the results are those of the unpadded network exactly.
+static const int kWidthUnit = 256;
+static const int kMaxWidth = 4096;
+static long long chunk_cap(const ikf_model* m);
 
 extern "C" const char* ikf_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ikf_abi_version(void) { return IKF_ABI_VERSION; }
@@ -107,7 +158,9 @@ static void free_exact(ikf_model* m) {
   if (m->ex_row_valid) (void)hipFree(m->ex_row_valid);
   if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
   if (m->ex_solved) (void)hipFree(m->ex_solved);
+  if (m->ex_block_scratch) (void)hipFree(m->ex_block_scratch);
   m->ex_q = nullptr; m->ex_row_valid = nullptr; m->ex_pose_idx = nullptr; m->ex_solved = nullptr;
+  m->ex_block_scratch = nullptr;
   m->exact_rows = m->exact_poses = 0;
 }
 
@@ -127,11 +180,12 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   if (desc->sigmoid_on_output && desc->dim_cond != 7)
     return fail(IKF_ERR_BAD_ARGUMENT, "sigmoid_on_output and softflow are incompatible, disable one or the other");
   if (desc->n_hidden < 1 || desc->n_hidden > 4) return fail(IKF_ERR_BAD_SHAPE, "ikf_create: Number of layers `n_layers` must be in [1, ..., 4]");
-  if (desc->width < 256 || desc->width % 256 != 0 || desc->width > 1024)
-    return fail(IKF_ERR_BAD_SHAPE, "ikf_create: coeff_fn_internal_size must be 256, 512, 768 or 1024 for the gfx950 kernels");
+  if (desc->width < 1 || desc->width > kMaxWidth)
+    return fail(IKF_ERR_BAD_SHAPE, "ikf_create: coeff_fn_internal_size must be in [1, 4096]");
   if (desc->ndof < 4 || desc->ndof > IKF_MAX_DOF || desc->ndof > D)
     return fail(IKF_ERR_BAD_SHAPE, "ikf_create: ndof must be in [4, 8] and <= dim");
-  IKF_HIP(hipSetDevice(device));
+  DeviceGuard dev_guard_(device);
+  if (dev_guard_.err != hipSuccess) return fail(IKF_ERR_HIP, std::string("hipSetDevice failed: ") + hipGetErrorString(dev_guard_.err));
 
   ikf_model* m = new ikf_model();
   m->device = device;
@@ -139,7 +193,7 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   m->dims.D = D;
   m->dims.L1 = D / 2;  // ikflow/model.py:336 (old FrEIA rule)
   m->dims.L2 = D - D / 2;
-  m->dims.width = desc->width;
+  m->dims.width = (desc->width + kWidthUnit - 1) / kWidthUnit * kWidthUnit;
   m->dims.n_hidden = desc->n_hidden;
   m->dims.ndof = desc->ndof;
   m->dims.n_pose = 7;
@@ -162,6 +216,9 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   if (e == hipSuccess) e = hipMemcpy(m->d_chain, &ch, sizeof(Chain), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&m->ex_count, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&m->h_count, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&m->d_split_flag, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(m->d_split_flag, 0, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&m->h_split_flag, sizeof(int));
   if (e != hipSuccess) {
     ikf_destroy(m);
     return fail(IKF_ERR_HIP, std::string("ikf_create: allocation failed: ") + hipGetErrorString(e));
@@ -172,7 +229,7 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
 
 extern "C" void ikf_destroy(ikf_model* m) {
   if (!m) return;
-  (void)hipSetDevice(m->device);
+  DeviceGuard dev_guard_(m->device);
   free_scratch(m);
   free_exact(m);
   if (m->arena) (void)hipFree(m->arena);
@@ -186,7 +243,10 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->d_collision) (void)hipFree(m->d_collision);
   if (m->ex_count) (void)hipFree(m->ex_count);
   if (m->h_count) (void)hipHostFree(m->h_count);
+  if (m->d_split_flag) (void)hipFree(m->d_split_flag);
+  if (m->h_split_flag) (void)hipHostFree(m->h_split_flag);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+  if (m->tail_event) (void)hipEventDestroy(m->tail_event);
   delete m;
 }
 
@@ -237,7 +297,7 @@ static ikf_status build_split_weights(ikf_model* m) {
   for (int si = 0; si < 2 * NB; ++si)
     for (int l = 0; l < d.n_hidden - 1; ++l, ++li) {
       uint16_t* dst = m->split_arena + li * per;
-      IKF_HIP(launch_split32_pack(m->subnets[si].w_mid[l], W, W, dst, nullptr));
+      IKF_HIP(launch_split32_pack(m->subnets[si].w_mid[l], W, W, dst, m->d_split_flag, nullptr));
       m->w_mid_split[(size_t)si * 3 + l] = dst;
     }
   // fragment-major copies for the small-batch kernel (same bytes again)
@@ -254,6 +314,18 @@ static ikf_status build_split_weights(ikf_model* m) {
       }
   }
   IKF_HIP(hipDeviceSynchronize());
+  // a weight beyond the f16 range cannot be split: the mode is refused (the f32 path is unaffected)
+  int wflag = 0;
+  IKF_HIP(hipMemcpy(&wflag, m->d_split_flag, sizeof(int), hipMemcpyDeviceToHost));
+  if (wflag != 0) {
+    IKF_HIP(hipMemset(m->d_split_flag, 0, sizeof(int)));
+    (void)hipFree(m->split_arena); m->split_arena = nullptr;
+    if (m->split_frag_arena) { (void)hipFree(m->split_frag_arena); m->split_frag_arena = nullptr; }
+    m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
+    m->w_mid_split_frag.assign((size_t)2 * NB * 3, nullptr);
+    m->precision = 0;
+    return fail(IKF_ERR_BAD_ARGUMENT, "f16x3 precision refused: a hidden Linear weight is non-finite or exceeds the f16 range (65504); staying on f32");
+  }
   return IKF_OK;
 }
 
@@ -281,13 +353,14 @@ static ikf_status build_frag_weights(ikf_model* m) {
 
 extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors) {
   if (!m || !tensors) return fail(IKF_ERR_NULL_POINTER, "ikf_load_weights: null argument");
-  IKF_HIP(hipSetDevice(m->device));
+  IKF_ON_DEVICE(m)
   std::unordered_map<std::string, const ikf_tensor*> idx;
   for (int i = 0; i < n_tensors; ++i)
     if (tensors[i].name) idx[tensors[i].name] = &tensors[i];
 
   const FlowDims& d = m->dims;
   const int D = d.D, W = d.width, NB = m->desc.nb_nodes, C = m->desc.dim_cond;
+  const int Wu = m->desc.width;  // width of the tensors in the file; W >= Wu is the padded width the kernels run at
   const int n_lin = d.n_hidden + 1;
 
   // pass 1: sizes
@@ -327,40 +400,42 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
       const std::string base = "module_list." + std::to_string(2 * b + 2 + moff) + ".subnet" + std::to_string(which) + ".";
       // first Linear: weight [W][n_x + C] -> transposed [n_x + 7][W] (+ softflow column apart)
       const ikf_tensor *tw = nullptr, *tb = nullptr;
-      st = need(idx, base + "0.weight", 0, {W, n_x + C}, &tw);
+      st = need(idx, base + "0.weight", 0, {Wu, n_x + C}, &tw);
       if (st != IKF_OK) return st;
-      st = need(idx, base + "0.bias", 0, {W}, &tb);
+      st = need(idx, base + "0.bias", 0, {Wu}, &tb);
       if (st != IKF_OK) return st;
       const float* w0 = static_cast<const float*>(tw->h_data);
       off_first[si] = cur;
       for (int k = 0; k < n_x + 7; ++k)
-        for (int c = 0; c < W; ++c) host[cur + (size_t)k * W + c] = w0[(size_t)c * (n_x + C) + k];
+        for (int c = 0; c < Wu; ++c) host[cur + (size_t)k * W + c] = w0[(size_t)c * (n_x + C) + k];
       cur += align64((size_t)(n_x + 7) * W);
       off_soft[si] = cur;
       if (C == 8)
-        for (int c = 0; c < W; ++c) host[cur + c] = w0[(size_t)c * (n_x + C) + n_x + 7];
+        for (int c = 0; c < Wu; ++c) host[cur + c] = w0[(size_t)c * (n_x + C) + n_x + 7];
       cur += align64(W);
       off_bfirst[si] = cur;
-      memcpy(&host[cur], tb->h_data, sizeof(float) * W);
+      memcpy(&host[cur], tb->h_data, sizeof(float) * Wu);
       cur += align64(W);
       for (int l = 1; l < d.n_hidden; ++l) {
-        st = need(idx, base + std::to_string(2 * l) + ".weight", 0, {W, W}, &tw);
+        st = need(idx, base + std::to_string(2 * l) + ".weight", 0, {Wu, Wu}, &tw);
         if (st != IKF_OK) return st;
-        st = need(idx, base + std::to_string(2 * l) + ".bias", 0, {W}, &tb);
+        st = need(idx, base + std::to_string(2 * l) + ".bias", 0, {Wu}, &tb);
         if (st != IKF_OK) return st;
         off_mid[si].push_back(cur);
-        memcpy(&host[cur], tw->h_data, sizeof(float) * (size_t)W * W);
+        for (int r = 0; r < Wu; ++r)
+          memcpy(&host[cur + (size_t)r * W], static_cast<const float*>(tw->h_data) + (size_t)r * Wu, sizeof(float) * Wu);
         cur += align64((size_t)W * W);
         off_bmid[si].push_back(cur);
-        memcpy(&host[cur], tb->h_data, sizeof(float) * W);
+        memcpy(&host[cur], tb->h_data, sizeof(float) * Wu);
         cur += align64(W);
       }
-      st = need(idx, base + std::to_string(2 * (n_lin - 1)) + ".weight", 0, {n_out, W}, &tw);
+      st = need(idx, base + std::to_string(2 * (n_lin - 1)) + ".weight", 0, {n_out, Wu}, &tw);
       if (st != IKF_OK) return st;
       st = need(idx, base + std::to_string(2 * (n_lin - 1)) + ".bias", 0, {n_out}, &tb);
       if (st != IKF_OK) return st;
       off_last[si] = cur;
-      memcpy(&host[cur], tw->h_data, sizeof(float) * (size_t)n_out * W);
+      for (int r = 0; r < n_out; ++r)
+        memcpy(&host[cur + (size_t)r * W], static_cast<const float*>(tw->h_data) + (size_t)r * Wu, sizeof(float) * Wu);
       cur += align64((size_t)n_out * W);
       off_blast[si] = cur;
       memcpy(&host[cur], tb->h_data, sizeof(float) * n_out);
@@ -375,6 +450,8 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
   ikf_status st = need(idx, "module_list.0.M_inv", 0, {D, D}, &tM);
   if (st != IKF_OK) return st;
   std::vector<float> blin(D, 0.f);
+  if (m->desc.sigmoid_on_output && !find_tensor(idx, "module_list.0.b"))  // the scaling node's offset is never zero
+    return fail(IKF_ERR_MISSING_TENSOR, "Missing key(s) in state_dict: \"module_list.0.b\"");
   if (const ikf_tensor* tb = find_tensor(idx, "module_list.0.b")) {
     if (tb->dtype != 0 || !tb->h_data) return fail(IKF_ERR_MISSING_TENSOR, "module_list.0.b has the wrong dtype");
     int64_t numel = 1;
@@ -425,8 +502,14 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
 // ---------------------------------------------------------------------------------------------------------------
 // scratch
 // ---------------------------------------------------------------------------------------------------------------
+static long long chunk_cap(const ikf_model* m) {  // rows per chunk: 16384 up to width 1024, fewer for wider subnets
+  const long long w = m->dims.width > 1024 ? m->dims.width : 1024;
+  return kMaxChunkRows * 1024 / w / 128 * 128;
+}
+
 static ikf_status ensure_scratch(ikf_model* m, long long rows) {
-  long long want = rows < kMaxChunkRows ? rows : kMaxChunkRows;
+  const long long cap = chunk_cap(m);
+  long long want = rows < cap ? rows : cap;
   want = (want + 127) / 128 * 128;  // the contraction kernels store whole 128-row tiles (no row predicate)
   if (want <= m->chunk_rows) return IKF_OK;
   free_scratch(m);
@@ -449,6 +532,7 @@ static ikf_status ensure_exact(ikf_model* m, long long poses, long long rows) {
     IKF_HIP(hipMalloc(&m->ex_row_valid, (size_t)nr));
     IKF_HIP(hipMalloc(&m->ex_pose_idx, sizeof(int) * (size_t)np));
     IKF_HIP(hipMalloc(&m->ex_solved, (size_t)np));
+    IKF_HIP(hipMalloc(&m->ex_block_scratch, sizeof(int) * 2 * (size_t)(compact_blocks(np) + 1)));
     m->exact_poses = np;
     m->exact_rows = nr;
   }
@@ -458,7 +542,7 @@ static ikf_status ensure_exact(ikf_model* m, long long poses, long long rows) {
 extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_reserve: null model");
   if (max_rows < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_reserve: max_rows must be positive");
-  IKF_HIP(hipSetDevice(m->device));
+  IKF_ON_DEVICE(m)
   return ensure_scratch(m, max_rows);
 }
 
@@ -535,6 +619,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     e.ps = ps; e.row0 = r0;
     e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
     e.width = d.width; e.slope = d.slope; e.h_out = m->hA; e.split_out = split ? 1 : 0;
+    e.split_flag = split ? m->d_split_flag : nullptr;
     IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     FusedGemmArgs g{};
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
@@ -551,6 +636,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
         sg.Wf = m->w_mid_split_frag.empty() ? nullptr : m->w_mid_split_frag[(size_t)(2 * b + which - 1) * 3 + l];
         sg.bias = w.b_mid[l]; sg.M = (int)nr; sg.N = d.width; sg.K = d.width; sg.slope = d.slope;
         sg.w_last = w.w_last; sg.n_out = w.n_out; sg.P_out = m->pbuf; sg.p_slot_stride = rows_pad * IKF_PSTRIDE;
+        sg.flag = m->d_split_flag;
         IKF_HIP(launch_split_gemm(last, scfg, sg, s));
       } else {
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
@@ -630,6 +716,9 @@ static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, l
   return IKF_OK;
 }
 
+static ikf_status run_flow_guarded(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
+                                   float* d_q_out, hipStream_t s);
+
 static ikf_status check_ready(ikf_model* m, const char* fn) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, std::string(fn) + ": null model");
   if (!m->loaded)
@@ -645,9 +734,14 @@ extern "C" ikf_status ikf_generate_approx(ikf_model* m, const float* d_poses, in
   if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_approx: n must be >= 0");
   if (n == 0) return IKF_OK;
   if (!d_poses || !d_latent || !d_q_out) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_approx: null device pointer");
-  IKF_HIP(hipSetDevice(m->device));
+  IKF_ON_DEVICE(m)
   PoseSource ps{d_poses, nullptr, pose_broadcast ? 1 : (long long)n, 7, softflow_scale};
-  return run_flow(m, ps, d_latent, n, clamp_to_limits, d_q_out, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  IKF_HIP(stream_enter(m, s));
+  st = run_flow_guarded(m, ps, d_latent, n, clamp_to_limits, d_q_out, s);
+  if (st != IKF_OK) return st;
+  IKF_HIP(stream_leave(m, s));
+  return IKF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -657,7 +751,7 @@ extern "C" ikf_status ikf_generate_approx(ikf_model* m, const float* d_poses, in
   if (!m) return fail(IKF_ERR_NULL_POINTER, fn ": null model");                      \
   if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, fn ": n must be >= 0");               \
   if (n == 0) return IKF_OK;                                                         \
-  IKF_HIP(hipSetDevice(m->device));                                                  \
+  IKF_ON_DEVICE(m)                                                                   \
   hipStream_t s = static_cast<hipStream_t>(stream);
 
 extern "C" ikf_status ikf_forward_kinematics(ikf_model* m, const float* d_q, int64_t n, float* d_poses_out, void* stream) {
@@ -724,7 +818,7 @@ extern "C" ikf_status ikf_set_collision_model(ikf_model* m, const ikf_capsule* h
     cm.pair_a[k] = (uint8_t)a;
     cm.pair_b[k] = (uint8_t)b;
   }
-  IKF_HIP(hipSetDevice(m->device));
+  IKF_ON_DEVICE(m)
   if (!m->d_collision) IKF_HIP(hipMalloc(&m->d_collision, sizeof(CollisionModel)));
   IKF_HIP(hipMemcpy(m->d_collision, &cm, sizeof(CollisionModel), hipMemcpyHostToDevice));
   return IKF_OK;
@@ -767,24 +861,60 @@ extern "C" ikf_status ikf_limits_exceeded(const float* d_q, int64_t n, int n_col
 // ---------------------------------------------------------------------------------------------------------------
 // exact IK
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t n,
-                                         const int32_t* repeat_counts, int n_rounds, int n_lm_steps,
-                                         float pos_thr, float rot_thr, ikf_latent_fn latent_fn, void* latent_user,
-                                         float* d_q_out, uint8_t* d_valid_out, int64_t* h_stats, void* stream) {
-  ikf_status st = check_ready(m, "ikf_generate_exact");
-  if (st != IKF_OK) return st;
-  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: n must be >= 0");
+// f16x3 range guard: read the overflow word after the flow of a call / round; true -> the caller re-runs on the f32 path
+static ikf_status split_overflowed(ikf_model* m, hipStream_t s, bool* out) {
+  *out = false;
+  if (m->precision != 1 || !m->split_arena || !m->d_split_flag) return IKF_OK;
+  IKF_HIP(hipMemcpyAsync(m->h_split_flag, m->d_split_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  IKF_HIP(hipStreamSynchronize(s));
+  if (*m->h_split_flag != 0) {
+    *out = true;
+    IKF_HIP(hipMemsetAsync(m->d_split_flag, 0, sizeof(int), s));
+  }
+  return IKF_OK;
+}
+
+// flow with the range guard applied (guard on + f16x3 mode: one flag read per call; out of range -> f32 re-run)
+static ikf_status run_flow_guarded(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
+                                   float* d_q_out, hipStream_t s) {
+  ikf_status st = run_flow(m, ps, d_latent, rows, clamp_limits, d_q_out, s);
+  if (st != IKF_OK || m->precision != 1 || !m->split_guard) return st;
+  bool bad = false;
+  st = split_overflowed(m, s, &bad);
+  if (st != IKF_OK || !bad) return st;
+  m->precision = 0;
+  st = run_flow(m, ps, d_latent, rows, clamp_limits, d_q_out, s);
+  m->precision = 1;
+  ++m->split_fallbacks;
+  return st;
+}
+
+// The retry schedule of generate_exact_ik_solutions (:345-411) over rounds of _generate_exact_ik_solutions (:119-247).
+// Seeds of a round come from the flow (latent_fn) or, for parity runs, from the caller (seed_fn).
+static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n, const int32_t* repeat_counts,
+                            int n_rounds, int n_lm_steps, float pos_thr, float rot_thr, ikf_latent_fn latent_fn,
+                            ikf_seed_fn seed_fn, void* user, float* d_q_out, uint8_t* d_valid_out, int64_t* h_stats,
+                            hipStream_t s, const char* fn) {
+  const std::string who(fn);
+  if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n must be >= 0");
   if (!repeat_counts || n_rounds < 1 || n_rounds > IKF_MAX_ROUNDS)
-    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: repeat_counts must hold 1..8 rounds");
-  if (n_lm_steps < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: n_lm_steps must be >= 1");
-  if (!latent_fn) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: latent_fn is required");
+    return fail(IKF_ERR_BAD_ARGUMENT, who + ": repeat_counts must hold 1..8 rounds");
+  if (n_lm_steps < 1) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n_lm_steps must be >= 1");
+  int max_repeat = 0;
+  for (int r = 0; r < n_rounds; ++r) {
+    if (repeat_counts[r] < 1) return fail(IKF_ERR_BAD_ARGUMENT, who + ": repeat counts must be >= 1");
+    max_repeat = repeat_counts[r] > max_repeat ? repeat_counts[r] : max_repeat;
+  }
   if (h_stats) memset(h_stats, 0, sizeof(int64_t) * 4 * n_rounds);
   if (n == 0) return IKF_OK;
-  if (!d_target_poses || !d_q_out || !d_valid_out) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: null device pointer");
-  if (n > 0x7fffffffLL / 64) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: n too large");
-  IKF_HIP(hipSetDevice(m->device));
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!d_target_poses || !d_q_out || !d_valid_out) return fail(IKF_ERR_NULL_POINTER, who + ": null device pointer");
+  if (n > 0x7fffffffLL / 64 || n * (long long)max_repeat > 0x7fffffffLL) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n too large");
   const int ndof = m->dims.ndof;
+  // the state of every round fits what round r could need at most (all n poses still unsolved): sized once, before any
+  // work is enqueued, so no allocation (= device-wide synchronisation) happens between the rounds
+  ikf_status st = ensure_exact(m, n, n * (long long)max_repeat);
+  if (st != IKF_OK) return st;
+  IKF_HIP(stream_enter(m, s));
 
   IKF_HIP(hipMemsetAsync(d_q_out, 0, sizeof(float) * (size_t)n * ndof, s));  // unsolved rows stay 0.0 (:197)
   IKF_HIP(hipMemsetAsync(d_valid_out, 0, (size_t)n, s));
@@ -792,24 +922,27 @@ extern "C" ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_pos
   long long n_active = n;
   for (int r = 0; r < n_rounds; ++r) {
     const int R = repeat_counts[r];
-    if (R < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_generate_exact: repeat counts must be >= 1");
-    st = ensure_exact(m, n, n_active * R);
-    if (st != IKF_OK) return st;
     // active pose list = ordered indices of still-invalid poses (identity in round 0)
-    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, s));
+    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, m->ex_block_scratch, s));
     if (r > 0) {
       IKF_HIP(hipMemcpyAsync(m->h_count, m->ex_count, sizeof(int), hipMemcpyDeviceToHost, s));
       IKF_HIP(hipStreamSynchronize(s));
       n_active = *m->h_count;
       if (h_stats) h_stats[4 * (r - 1) + 3] = h_stats[4 * (r - 1) + 0] - n_active;
-      if (n_active == 0) return IKF_OK;  // everything converged (:383-385, :402-408)
+      if (n_active == 0) break;  // everything converged (:383-385, :402-408)
     }
     const long long rows = n_active * R;
-    const float* d_latent = latent_fn(latent_user, r, rows, m->dims.D);
-    if (!d_latent) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: latent_fn returned null");
-    PoseSource ps{d_target_poses, m->ex_pose_idx, n_active, 7, 0.0f};
-    st = run_flow(m, ps, d_latent, rows, /*clamp=*/1, m->ex_q, s);  // seeds (:188)
-    if (st != IKF_OK) return st;
+    if (seed_fn) {
+      const float* d_seeds = seed_fn(user, r, n_active, R, m->ex_pose_idx, ndof);
+      if (!d_seeds) return fail(IKF_ERR_NULL_POINTER, who + ": seed_fn returned null");
+      IKF_HIP(hipMemcpyAsync(m->ex_q, d_seeds, sizeof(float) * (size_t)rows * ndof, hipMemcpyDeviceToDevice, s));
+    } else {
+      const float* d_latent = latent_fn(user, r, rows, m->dims.D);
+      if (!d_latent) return fail(IKF_ERR_NULL_POINTER, who + ": latent_fn returned null");
+      PoseSource ps{d_target_poses, m->ex_pose_idx, n_active, 7, 0.0f};
+      st = run_flow_guarded(m, ps, d_latent, rows, /*clamp=*/1, m->ex_q, s);  // seeds (:188)
+      if (st != IKF_OK) return st;
+    }
     IKF_HIP(hipMemsetAsync(m->ex_solved, 0, (size_t)n_active, s));
     for (int it = 0; it < n_lm_steps; ++it) {
       IKF_HIP(launch_exact_lm_iter(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, m->ex_q,
@@ -823,13 +956,60 @@ extern "C" ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_pos
       h_stats[4 * r + 2] = rows * n_lm_steps;  // upper bound: rows of poses solved early are masked out
     }
   }
-  if (h_stats) {
-    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, s));
+  if (h_stats && n_active > 0) {
+    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, m->ex_block_scratch, s));
     IKF_HIP(hipMemcpyAsync(m->h_count, m->ex_count, sizeof(int), hipMemcpyDeviceToHost, s));
     IKF_HIP(hipStreamSynchronize(s));
     h_stats[4 * (n_rounds - 1) + 3] = h_stats[4 * (n_rounds - 1) + 0] - *m->h_count;
   }
+  IKF_HIP(stream_leave(m, s));
   return IKF_OK;
+}
+
+extern "C" ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t n,
+                                         const int32_t* repeat_counts, int n_rounds, int n_lm_steps,
+                                         float pos_thr, float rot_thr, ikf_latent_fn latent_fn, void* latent_user,
+                                         float* d_q_out, uint8_t* d_valid_out, int64_t* h_stats, void* stream) {
+  ikf_status st = check_ready(m, "ikf_generate_exact");
+  if (st != IKF_OK) return st;
+  if (!latent_fn) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact: latent_fn is required");
+  IKF_ON_DEVICE(m)
+  return run_exact(m, d_target_poses, n, repeat_counts, n_rounds, n_lm_steps, pos_thr, rot_thr, latent_fn, nullptr,
+                   latent_user, d_q_out, d_valid_out, h_stats, static_cast<hipStream_t>(stream), "ikf_generate_exact");
+}
+
+extern "C" ikf_status ikf_generate_exact_seeded(ikf_model* m, const float* d_target_poses, int64_t n,
+                                                const int32_t* repeat_counts, int n_rounds, int n_lm_steps,
+                                                float pos_thr, float rot_thr, ikf_seed_fn seed_fn, void* seed_user,
+                                                float* d_q_out, uint8_t* d_valid_out, int64_t* h_stats, void* stream) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact_seeded: null model");
+  if (!seed_fn) return fail(IKF_ERR_NULL_POINTER, "ikf_generate_exact_seeded: seed_fn is required");
+  IKF_ON_DEVICE(m)
+  return run_exact(m, d_target_poses, n, repeat_counts, n_rounds, n_lm_steps, pos_thr, rot_thr, nullptr, seed_fn,
+                   seed_user, d_q_out, d_valid_out, h_stats, static_cast<hipStream_t>(stream),
+                   "ikf_generate_exact_seeded");
+}
+
+static const float* fixed_seeds(void* user, int, int64_t, int, const int32_t*, int) { return static_cast<const float*>(user); }
+
+extern "C" ikf_status ikf_refine_exact(ikf_model* m, const float* d_target_poses, int64_t n, int repeat,
+                                       const float* d_seeds_q, int n_lm_steps, float pos_thr, float rot_thr,
+                                       float* d_q_out, uint8_t* d_valid_out, void* stream) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_refine_exact: null model");
+  if (n > 0 && !d_seeds_q) return fail(IKF_ERR_NULL_POINTER, "ikf_refine_exact: null device pointer");
+  IKF_ON_DEVICE(m)
+  const int32_t rc[1] = {repeat};
+  return run_exact(m, d_target_poses, n, rc, 1, n_lm_steps, pos_thr, rot_thr, nullptr, fixed_seeds,
+                   const_cast<float*>(d_seeds_q), d_q_out, d_valid_out, nullptr, static_cast<hipStream_t>(stream),
+                   "ikf_refine_exact");
+}
+
+extern "C" ikf_status ikf_reserve_exact(ikf_model* m, int64_t max_poses, int max_repeat) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_reserve_exact: null model");
+  if (max_poses < 1 || max_repeat < 1 || max_poses * (long long)max_repeat > 0x7fffffffLL)
+    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_reserve_exact: max_poses and max_repeat must be positive (product < 2^31)");
+  IKF_ON_DEVICE(m)
+  return ensure_exact(m, max_poses, max_poses * (long long)max_repeat);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -840,7 +1020,7 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
   if (st != IKF_OK) return st;
   if (!ms_out || rows < 1 || iters < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_time_gemm: bad argument");
   if (m->dims.n_hidden < 2) return fail(IKF_ERR_BAD_SHAPE, "ikf_time_gemm: model has no width x width layer");
-  IKF_HIP(hipSetDevice(m->device));
+  IKF_ON_DEVICE(m)
   hipStream_t s = static_cast<hipStream_t>(stream);
   st = ensure_scratch(m, rows);
   if (st != IKF_OK) return st;
@@ -886,7 +1066,7 @@ extern "C" ikf_status ikf_profile_begin(ikf_model* m) {
 
 extern "C" ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream) {
   if (!m || !n_launches || !total_ms) return fail(IKF_ERR_NULL_POINTER, "ikf_profile_end: null argument");
-  IKF_HIP(hipSetDevice(m->device));
+  IKF_ON_DEVICE(m)
   hipStream_t s = static_cast<hipStream_t>(stream);
   m->prof_on = false;
   // calibrate what an (otherwise empty) event pair measures on this stream and take it off every bracketed launch
@@ -928,9 +1108,28 @@ extern "C" ikf_status ikf_set_precision(ikf_model* m, int mode) {
     return fail(IKF_ERR_BAD_SHAPE, "ikf_set_precision: the f16-split contraction needs a width that is a multiple of 128 and >= 2 hidden layers");
   m->precision = mode;
   if (mode == 1) {
-    IKF_HIP(hipSetDevice(m->device));
+    IKF_ON_DEVICE(m)
     return build_split_weights(m);
   }
   return IKF_OK;
 }
 extern "C" int ikf_get_precision(const ikf_model* m) { return m ? m->precision : -1; }
+
+extern "C" ikf_status ikf_set_split_guard(ikf_model* m, int guard) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_split_guard: null model");
+  if (guard != 0 && guard != 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_split_guard: guard must be 0 or 1");
+  m->split_guard = guard;
+  return IKF_OK;
+}
+extern "C" int64_t ikf_split_fallback_count(const ikf_model* m) { return m ? (int64_t)m->split_fallbacks : 0; }
+extern "C" int ikf_split_overflow_pending(ikf_model* m, void* stream) {
+  if (!m) return 0;
+  DeviceGuard dev_guard_(m->device);
+  if (dev_guard_.err != hipSuccess) return 0;
+  bool bad = false;
+  const int saved = m->precision;
+  if (m->split_arena) m->precision = 1;  // the flag is meaningful whenever the split images exist
+  (void)split_overflowed(m, static_cast<hipStream_t>(stream), &bad);
+  m->precision = saved;
+  return bad ? 1 : 0;
+}

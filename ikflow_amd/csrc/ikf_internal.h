@@ -101,6 +101,7 @@ struct EntryArgs {      // k_subnet_entry: pending coupling + first Linear of th
   float slope;
   float* h_out;         // [rows_pad][width]  fp32, or the f16 hi/lo split image when split_out != 0
   int split_out;
+  int* split_flag;      // split_out: OR'ed with 1 when an activation is non-finite or beyond the f16 range (65504)
 };
 struct FusedGemmArgs {
   // contraction C = lrelu(A . W^T + bias), K = N = width
@@ -157,7 +158,10 @@ struct SplitGemmArgs {
   int n_out;
   float* P_out;
   long long p_slot_stride;
+  int* flag;            // OR'ed with 1 when an activation written to C is non-finite or beyond the f16 range
 };
+// true when a does not fit the f16 hi part of the split (|a| > 65504, inf, NaN)
+__device__ __forceinline__ bool split_out_of_range(float a) { return !(__builtin_fabsf(a) <= 65504.0f); }
 hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s);
 int split_pick_cfg(long long rows, int width);
 int split_slots(int cfg, int width);
@@ -167,7 +171,7 @@ void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // ho
 int fused_skinny_cfg();
 int fused_skinny32_cfg();
 hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream_t s);
-hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, hipStream_t s);
+hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, int* d_flag, hipStream_t s);
 const char* split_kernel_name();
 
 // kin_kernels.hip
@@ -209,6 +213,9 @@ hipError_t launch_exact_lm_iter(const Chain* d_chain, int ndof, const float* pos
 hipError_t launch_exact_select(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
                                const uint8_t* row_valid, uint8_t* solved, float* q_out, uint8_t* valid_out,
                                hipStream_t s);
-hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, hipStream_t s);
+// ordered list of the indices with valid[i] == 0 and their count; block_scratch: 2 * compact_blocks(n) ints
+long long compact_blocks(long long n);
+hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, int* block_scratch,
+                                  hipStream_t s);
 
 }  // namespace ikf

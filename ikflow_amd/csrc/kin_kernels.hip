@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void k_exact_select(int ndof, const int* __res
   }
 }
 
-// ordered compaction of the indices with valid[i] == 0 (boolean-mask indexing, ikflow_solver.py:389); single workgroup
+// ordered compaction of the indices with valid[i] == 0 (boolean-mask indexing, ikflow_solver.py:389).
+// Up to kCompactSingle poses: one workgroup (one launch - the exact path is a latency chain at these sizes).
 __global__ __launch_bounds__(1024) void k_compact_invalid(const uint8_t* __restrict__ valid, long long n,
                                                           int* __restrict__ idx_out, int* __restrict__ count_out) {
   __shared__ int part[1024];
@@ -512,6 +513,81 @@ __global__ __launch_bounds__(1024) void k_compact_invalid(const uint8_t* __restr
   for (long long i = b; i < e; ++i)
     if (!valid[i]) idx_out[pos++] = (int)i;
   if (t == 1023) *count_out = part[1023];
+}
+
+// Larger batches (the 1M-pose sharded exact path): three short launches over 4096-pose blocks - per-block counts, an
+// exclusive scan of the block counts by one workgroup, ordered per-block writes.  Thread t of a block owns 16 consecutive
+// poses, so thread order = pose order.
+constexpr int kCompactSingle = 32768;
+constexpr int kCompactPerThread = 16;
+constexpr int kCompactBlock = 256 * kCompactPerThread;
+
+__device__ __forceinline__ int compact_thread_count(const uint8_t* __restrict__ valid, long long n, long long base) {
+  int c = 0;
+#pragma unroll
+  for (int i = 0; i < kCompactPerThread; ++i)
+    if (base + i < n && !valid[base + i]) ++c;
+  return c;
+}
+
+// exclusive prefix of `c` over the 256 threads of the block (scan[] = 256 ints of LDS); returns the block total via *total
+__device__ __forceinline__ int block_exclusive_scan_256(int c, int* scan, int* total) {
+  const int t = threadIdx.x;
+  scan[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = (t >= off) ? scan[t - off] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  *total = scan[255];
+  return scan[t] - c;
+}
+
+__global__ __launch_bounds__(256) void k_compact_count(const uint8_t* __restrict__ valid, long long n,
+                                                       int* __restrict__ block_count) {
+  __shared__ int scan[256];
+  const long long base = (long long)blockIdx.x * kCompactBlock + (long long)threadIdx.x * kCompactPerThread;
+  int total;
+  (void)block_exclusive_scan_256(compact_thread_count(valid, n, base), scan, &total);
+  if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_compact_offsets(const int* __restrict__ block_count, int nb,
+                                                          int* __restrict__ block_off, int* __restrict__ count_out) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (nb + 1023) / 1024;
+  const int b = t * per;
+  const int e = (b + per < nb) ? b + per : nb;
+  int c = 0;
+  for (int i = b; i < e; ++i) c += block_count[i];
+  part[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - c;
+  for (int i = b; i < e; ++i) {
+    block_off[i] = run;
+    run += block_count[i];
+  }
+  if (t == 1023) *count_out = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_compact_write(const uint8_t* __restrict__ valid, long long n,
+                                                       const int* __restrict__ block_off, int* __restrict__ idx_out) {
+  __shared__ int scan[256];
+  const long long base = (long long)blockIdx.x * kCompactBlock + (long long)threadIdx.x * kCompactPerThread;
+  int total;
+  int pos = block_off[blockIdx.x] + block_exclusive_scan_256(compact_thread_count(valid, n, base), scan, &total);
+#pragma unroll
+  for (int i = 0; i < kCompactPerThread; ++i)
+    if (base + i < n && !valid[base + i]) idx_out[pos++] = (int)(base + i);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -605,8 +681,19 @@ hipError_t launch_exact_select(int ndof, const int* pose_idx, int n_active, int 
                      repeat, q, row_valid, solved, q_out, valid_out);
   return hipGetLastError();
 }
-hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, hipStream_t s) {
-  hipLaunchKernelGGL(k_compact_invalid, dim3(1), dim3(1024), 0, s, valid, n, idx_out, count_out);
+long long compact_blocks(long long n) { return (n + kCompactBlock - 1) / kCompactBlock; }
+hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, int* block_scratch,
+                                  hipStream_t s) {
+  if (n <= kCompactSingle || block_scratch == nullptr) {
+    hipLaunchKernelGGL(k_compact_invalid, dim3(1), dim3(1024), 0, s, valid, n, idx_out, count_out);
+    return hipGetLastError();
+  }
+  const int nb = (int)compact_blocks(n);
+  int* counts = block_scratch;
+  int* offs = block_scratch + nb;
+  hipLaunchKernelGGL(k_compact_count, dim3(nb), dim3(256), 0, s, valid, n, counts);
+  hipLaunchKernelGGL(k_compact_offsets, dim3(1), dim3(1024), 0, s, counts, nb, offs, count_out);
+  hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(256), 0, s, valid, n, offs, idx_out);
   return hipGetLastError();
 }
 

@@ -59,7 +59,17 @@ def sharded_rows(
 
 
 def sharded_generate_ik_solutions(solver, target_poses: torch.Tensor, latent: Optional[torch.Tensor] = None, group=None, **kw):
-    """generate_ik_solutions over rows sharded across the ranks of `group`; returns the full [n x ndof] on every rank."""
+    """generate_ik_solutions over rows sharded across the ranks of `group`; returns the full [n x ndof] on every rank.
+
+    When `latent` is None the FULL [n x D] latent is drawn on every rank with the reference's own call
+    (draw_latent -> torch's global generator on the pose device, ikflow_solver.py:16-29,341) and each rank keeps its
+    block: with the usual identical seed on every rank the result equals the single-process call on the same seed, and
+    no two shards ever see the same latent block."""
+    if latent is None:
+        from ikflow_amd.ikflow_solver import draw_latent
+
+        latent = draw_latent(kw.get("latent_distribution", "gaussian"), kw.get("latent_scale", 1.0),
+                             (target_poses.shape[0], solver.network_width), target_poses.device)
 
     def compute(p, l):
         return solver.generate_ik_solutions(p, n=(1 if p.shape[0] == 1 else None), latent=l, **kw)

@@ -158,6 +158,10 @@ class Engine:
     def reserve(self, max_rows: int) -> None:
         _check(self.lib.ikf_reserve(self._h, int(max_rows)))
 
+    def reserve_exact(self, max_poses: int, max_repeat: int = 10) -> None:
+        """Pre-size the exact-IK state (max_poses * max_repeat LM rows) so that generate_exact allocates nothing."""
+        _check(self.lib.ikf_reserve_exact(self._h, int(max_poses), int(max_repeat)))
+
     PRECISIONS = {"f32": 0, "f16x3": 1}
 
     def set_precision(self, mode: str) -> None:
@@ -167,6 +171,18 @@ class Engine:
     @property
     def precision(self) -> str:
         return {v: k for k, v in self.PRECISIONS.items()}[self.lib.ikf_get_precision(self._h)]
+
+    def set_split_guard(self, on: bool) -> None:
+        """f16x3 range guard (include/ikflow_amd.h ikf_set_split_guard): on (default) = one 4-byte flag read per call and an
+        automatic f32 re-run when a hidden activation left the f16 range; off = no synchronisation, no re-run."""
+        _check(self.lib.ikf_set_split_guard(self._h, 1 if on else 0))
+
+    @property
+    def split_fallback_count(self) -> int:
+        return int(self.lib.ikf_split_fallback_count(self._h))
+
+    def split_overflow_pending(self) -> bool:
+        return bool(self.lib.ikf_split_overflow_pending(self._h, self._stream()))
 
     def set_gemm_variant(self, variant: int) -> None:
         _check(self.lib.ikf_set_gemm_variant(self._h, int(variant)))
@@ -276,11 +292,14 @@ class Engine:
         latents: Optional[Sequence[torch.Tensor]] = None,
         n_lm_steps: int = 3,
         return_stats: bool = False,
+        seed_fn=None,
     ):
         """Returns (solutions [n x ndof] f32, valids [n] bool) (+ stats [rounds x 4] if asked).
 
         ``latents``: optional per-round latent tensors ([>= n_r*R_r x D], tile-major) for parity runs; when None each
-        round draws ``torch.randn((n_tiled, D), device=...)`` exactly like draw_latent() (ikflow_solver.py:187)."""
+        round draws ``torch.randn((n_tiled, D), device=...)`` exactly like draw_latent() (ikflow_solver.py:187).
+        ``seed_fn(round, active_idx [n_active] int64 device tensor, repeat) -> [n_active * repeat x ndof]``: parity runs with
+        the flow taken out (ikf_generate_exact_seeded) - the returned seeds replace the flow's output of that round."""
         tp = self._on_device(target_poses, "target_poses")
         assert tp.ndim == 2 and tp.shape[1] == 7, f"target_poses must be of shape [n x 7], got {tuple(tp.shape)}"
         n = tp.shape[0]
@@ -306,15 +325,36 @@ class Engine:
                 err.append(e)
                 return 0
 
-        cb = _lib.LATENT_FN(_latent_cb)
+        def _seed_cb(_user, rnd, n_active, repeat, _d_idx, ndof):
+            try:
+                # the still-unsolved poses, ascending: the same list the engine built (its stream is idle here)
+                idx = torch.arange(n, device=self.device) if rnd == 0 else torch.nonzero(valid == 0)[:, 0]
+                assert idx.numel() == n_active, (idx.numel(), n_active)
+                sq = self._on_device(seed_fn(rnd, idx, repeat), f"seeds of round {rnd}")
+                assert sq.shape == (n_active * repeat, ndof), f"seeds of round {rnd} must be [{n_active * repeat} x {ndof}], got {tuple(sq.shape)}"
+                keep.append(sq)
+                return sq.data_ptr()  # produced on the stream the engine enqueues its copy on: ordered
+            except BaseException as e:
+                err.append(e)
+                return 0
+
         rc = (C.c_int32 * nr)(*[int(r) for r in repeat_counts])
         stats = (C.c_int64 * (4 * nr))()
         with torch.cuda.device(self.device):
-            code = self.lib.ikf_generate_exact(
-                self._h, tp.data_ptr(), n, rc, nr, int(n_lm_steps), float(pos_error_threshold),
-                float(rot_error_threshold), cb, None, sols.data_ptr(), valid.data_ptr(),
-                stats if return_stats else None, self._stream(),
-            )
+            if seed_fn is not None:
+                cb = _lib.SEED_FN(_seed_cb)
+                code = self.lib.ikf_generate_exact_seeded(
+                    self._h, tp.data_ptr(), n, rc, nr, int(n_lm_steps), float(pos_error_threshold),
+                    float(rot_error_threshold), cb, None, sols.data_ptr(), valid.data_ptr(),
+                    stats if return_stats else None, self._stream(),
+                )
+            else:
+                cb = _lib.LATENT_FN(_latent_cb)
+                code = self.lib.ikf_generate_exact(
+                    self._h, tp.data_ptr(), n, rc, nr, int(n_lm_steps), float(pos_error_threshold),
+                    float(rot_error_threshold), cb, None, sols.data_ptr(), valid.data_ptr(),
+                    stats if return_stats else None, self._stream(),
+                )
         if err:
             raise err[0]
         _check(code)
@@ -325,6 +365,21 @@ class Engine:
         if return_stats:
             return out + (np.array(list(stats), dtype=np.int64).reshape(nr, 4),)
         return out
+
+    def refine_exact(self, target_poses: torch.Tensor, seeds_q: torch.Tensor, repeat: int, pos_error_threshold: float,
+                     rot_error_threshold: float, n_lm_steps: int = 3) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One round of _generate_exact_ik_solutions (ikflow_solver.py:119-247) given its flow output: seeds_q
+        [n * repeat x ndof] tile-major -> (solutions [n x ndof], valids [n] bool)."""
+        tp = self._on_device(target_poses, "target_poses")
+        sq = self._q(seeds_q)
+        n = tp.shape[0]
+        assert tp.ndim == 2 and tp.shape[1] == 7 and sq.shape[0] == n * repeat, (tuple(tp.shape), tuple(sq.shape), repeat)
+        sols = torch.empty((n, self.layout.ndof), dtype=torch.float32, device=self.device)
+        valid = torch.empty(n, dtype=torch.uint8, device=self.device)
+        _check(self.lib.ikf_refine_exact(self._h, tp.data_ptr(), n, int(repeat), sq.data_ptr(), int(n_lm_steps),
+                                         float(pos_error_threshold), float(rot_error_threshold), sols.data_ptr(),
+                                         valid.data_ptr(), self._stream()))
+        return sols, valid.to(torch.bool)
 
     # -- measurement ---------------------------------------------------------------------------------
     def time_gemm(self, rows: int, iters: int) -> float:
@@ -353,14 +408,19 @@ class Engine:
 # ---------------------------------------------------------------------------------------------------
 # kinematics-only engines for Robot.forward_kinematics & co (no flow weights needed)
 # ---------------------------------------------------------------------------------------------------
-_KIN_CACHE: Dict[Tuple[str, int], Engine] = {}
+_KIN_CACHE: Dict[Tuple, Engine] = {}
+
+
+def _robot_key(robot: Robot) -> Tuple:
+    """Two robots share an engine only when their chains and limits are the same, whatever their names."""
+    return (robot.name, tuple((j.kind, j.origin_xyz, j.origin_rpy, j.axis, j.limits) for j in robot.joints))
 
 
 def kinematics_engine_for(robot: Robot, device=None) -> Engine:
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if not torch.cuda.is_available():
         raise EngineError("no GPU visible: ikflow_amd kinematics run on the MI355X only (there is no CPU path)")
-    key = (robot.name, _dev_index(dev))
+    key = (_robot_key(robot), _dev_index(dev))
     if key not in _KIN_CACHE:
         lay = FlowLayout(nb_nodes=1, dim=max(robot.ndof, 2), dim_cond=8, width=256, n_hidden=1, clamp=2.5, ndof=robot.ndof)
         _KIN_CACHE[key] = Engine(lay, robot, dev)

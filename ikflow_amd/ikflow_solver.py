@@ -103,8 +103,11 @@ class IKFlowSolver:
         """The C-ABI handle for `device` (created lazily; weights are uploaded when it is created)."""
         from ikflow_amd.engine import Engine  # imports the ctypes binding: fails loudly without the built library
 
+        from ikflow_amd.engine import _dev_index
+
         device = torch.device(config.DEVICE if device is None else device)
-        if self._engine is None or self._engine.device != torch.device("cuda", device.index or 0):
+        # an index-less "cuda" means torch's current device (what Engine resolves it to)
+        if self._engine is None or self._engine.device != torch.device("cuda", _dev_index(device)):
             eng = Engine(self._layout, self._robot, device)
             if self._state_dict_np is not None:
                 eng.load_state_dict(self._state_dict_np)

@@ -251,6 +251,11 @@ def validate_state_dict(layout: FlowLayout, sd: Dict[str, np.ndarray]) -> None:
             missing.append(k)
         elif tuple(sd[k].shape) != (layout.dim, layout.dim):
             bad.append((k, tuple(sd[k].shape), (layout.dim, layout.dim)))
+    if layout.sigmoid_on_output:  # the scaling node's offset b = -slope * lo is never zero: a file without it is broken
+        if "module_list.0.b" not in sd:
+            missing.append("module_list.0.b")
+        elif int(np.prod(sd["module_list.0.b"].shape)) != layout.dim:
+            bad.append(("module_list.0.b", tuple(sd["module_list.0.b"].shape), (1, layout.dim)))
     off = layout.module_offset
     for i in range(layout.nb_nodes):
         k = key_perm_inv(i, off)

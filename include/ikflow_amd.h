@@ -17,7 +17,12 @@
  *   - all matrices are row-major fp32; poses are [x y z qw qx qy qz] (ikflow README.md:76).
  *   - every function returns an ikf_status; ikf_last_error() returns a thread-local message for the last failure.
  *   - a handle is NOT thread-safe; use one handle per device.  Work is enqueued on the given stream; the approx
- *     path never synchronises, the exact path synchronises once per retry round to read a 4-byte count.
+ *     path never synchronises (exception: the opt-in f16x3 precision with its range guard on reads one 4-byte flag per
+ *     call), the exact path synchronises once per retry round to read a 4-byte count.
+ *   - every entry point runs on the handle's device and restores the caller's current device before it returns.
+ *   - the handle's scratch is shared by all of its calls.  Calls may arrive on different streams: a call on another
+ *     stream than the previous one first waits (hipStreamWaitEvent) for the previous call's work; calls are never
+ *     concurrent on one handle.  Use one handle per stream for concurrency.
  *   - the library owns: the handle, the packed weights and its scratch.  ikf_reserve() pre-sizes scratch so that
  *     steady-state calls allocate nothing.
  */
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define IKF_ABI_VERSION 2
+#define IKF_ABI_VERSION 3
 #define IKF_MAX_DOF 8     /* actuated joints on the chain                      */
 #define IKF_MAX_DIM 16    /* flow width D (dim_latent_space)                   */
 #define IKF_MAX_ROUNDS 8  /* len(repeat_counts)                                */
@@ -61,7 +66,8 @@ typedef struct ikf_model_desc {
   int32_t nb_nodes;           /* coupling blocks                     model.py:338                   */
   int32_t dim;                /* D = dim_latent_space                ikflow_solver.py:54            */
   int32_t dim_cond;           /* 8 (softflow) or 7                   ikflow_solver.py:51-53         */
-  int32_t width;              /* coeff_fn_internal_size              model.py:297                   */
+  int32_t width;              /* coeff_fn_internal_size, 1..4096     model.py:297  (run at the next multiple
+                                 of 256 with zero padding - exact)                                    */
   int32_t n_hidden;           /* coeff_fn_config (1..4)              model.py:59                    */
   float clamp;                /* rnvp_clamp                          model.py:347                   */
   float leaky_slope;          /* 0.01                                model.py:63                    */
@@ -93,13 +99,18 @@ const char* ikf_last_error(void);
 int ikf_abi_version(void);
 
 /* Replaces IKFlowSolver.load_state_dict (ikflow_solver.py:413-429): packs the tensors once into the kernels'
- * HBM layout.  Required keys: module_list.0.M_inv [D,D]; optional module_list.0.b [1,D]; per block i:
+ * HBM layout.  Required keys: module_list.0.M_inv [D,D]; module_list.0.b [1,D] (optional = 0 for the plain graph,
+ * required for the sigmoid_on_output graph whose scaling node has a non-zero offset); per block i:
  * module_list.{2i+1}.perm_inv [D] (int64), module_list.{2i+2}.subnet{1,2}.{0,2,..}.{weight,bias}. */
 ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors);
 int ikf_weights_loaded(const ikf_model* m);
 
-/* Pre-size scratch for batches of up to max_rows flow rows (and the LM state for exact IK). */
+/* Pre-size the flow scratch for batches of up to max_rows flow rows. */
 ikf_status ikf_reserve(ikf_model* m, int64_t max_rows);
+/* Pre-size the exact-IK state for calls of up to max_poses target poses with repeat counts up to max_repeat
+ * (max_poses * max_repeat LM rows), so that ikf_generate_exact allocates nothing.  Without it the first call sizes the
+ * state for its own worst case (n * max(repeat_counts) rows) before any work is enqueued. */
+ikf_status ikf_reserve_exact(ikf_model* m, int64_t max_poses, int max_repeat);
 
 /* -- approximate IK: replaces IKFlowSolver._run_inference (ikflow_solver.py:85-110) ----------------------- */
 /* d_poses: [n x 7], or a single pose [7] when pose_broadcast != 0 (the `y.expand((n,7))` form, :333-336).
@@ -171,6 +182,26 @@ ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t
                               ikf_latent_fn latent_fn, void* latent_user, float* d_q_out, uint8_t* d_valid_out,
                               int64_t* h_stats, void* stream);
 
+/* The same retry schedule with the flow taken out (parity runs: "identical seeds in"): round `round`'s seeds come from
+ * the callback instead of the flow.  d_active_idx [n_active] (device, int32, ascending) lists the target poses that are
+ * still unsolved; the callback returns a DEVICE pointer to [n_active * repeat x ndof] fp32 clamped seeds laid out
+ * tile-major (row = r * n_active + j  <->  repeat r of pose d_active_idx[j]; `conditional.repeat((R,1))`, :185).  The
+ * stream is idle when the callback runs in rounds > 0 (the count was just read); in round 0 every pose is active.
+ * Everything after `self._run_inference` (:188) is exercised: LM iterations (:199-209), validity (:210-211), "highest
+ * valid repeat wins" (:217-222), slot order (:224-225), compaction (:231-233) and the retry rounds (:383-408).
+ * Needs no weights. */
+typedef const float* (*ikf_seed_fn)(void* user, int round, int64_t n_active, int repeat, const int32_t* d_active_idx,
+                                    int ndof);
+ikf_status ikf_generate_exact_seeded(ikf_model* m, const float* d_target_poses, int64_t n, const int32_t* repeat_counts,
+                                     int n_rounds, int n_lm_steps, float pos_error_threshold, float rot_error_threshold,
+                                     ikf_seed_fn seed_fn, void* seed_user, float* d_q_out, uint8_t* d_valid_out,
+                                     int64_t* h_stats, void* stream);
+/* One round = IKFlowSolver._generate_exact_ik_solutions (:119-247) given its flow output: d_seeds_q [n * repeat x ndof]
+ * (tile-major, not modified) -> d_q_out [n x ndof], d_valid_out [n]. */
+ikf_status ikf_refine_exact(ikf_model* m, const float* d_target_poses, int64_t n, int repeat, const float* d_seeds_q,
+                            int n_lm_steps, float pos_error_threshold, float rot_error_threshold, float* d_q_out,
+                            uint8_t* d_valid_out, void* stream);
+
 /* -- measurement hooks (bench.py / tests) -------------------------------------------------------------------- */
 /* Time `iters` launches of the dominant kernel (the width x width fused Linear+LeakyReLU contraction) on M rows with
  * hipEvents on `stream`; returns average milliseconds per launch in *ms_out. */
@@ -188,9 +219,20 @@ double ikf_profile_event_overhead_ms(const ikf_model* m);
  *   0 = exact f32 on v_mfma_f32_32x32x2_f32 (default);
  *   1 = error-compensated f16 split on v_mfma_f32_32x32x16_f16 (a = hi + lo/2048 for both operands, three products,
  *       fp32 accumulate): measured closer to fp64 than mode 0 (tools/split_probe.hip), ~5x less matrix-pipe time;
- *       hidden activations must stay below 65504 in magnitude. Everything else stays fp32 in both modes. */
+ *       Everything else stays fp32 in both modes.  f16 holds magnitudes up to 65504: every kernel that produces a split
+ *       operand ORs a flag into a device word when a hidden activation is non-finite or exceeds that range (see
+ *       ikf_set_split_guard). */
 ikf_status ikf_set_precision(ikf_model* m, int mode);
 int ikf_get_precision(const ikf_model* m);
+/* Range guard of mode 1.  guard = 1 (default): at the end of every call the engine reads the overflow flag (one 4-byte
+ * copy + stream synchronisation); if it is set the whole call is run again on the exact-f32 path, so the caller never
+ * sees an out-of-range result, and the event is counted.  guard = 0: no synchronisation and no re-run; the flag keeps
+ * accumulating on the device and ikf_split_overflow_pending() reads and clears it (synchronises `stream`). */
+ikf_status ikf_set_split_guard(ikf_model* m, int guard);
+/* Number of calls re-run on the f32 path because the f16 range was exceeded (guard = 1). */
+int64_t ikf_split_fallback_count(const ikf_model* m);
+/* 1 if an activation left the f16 range since the last check (then cleared), 0 if not; synchronises `stream`. */
+int ikf_split_overflow_pending(ikf_model* m, void* stream);
 const char* ikf_split_kernel_name(void);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
 const char* ikf_dominant_kernel_name(void);
