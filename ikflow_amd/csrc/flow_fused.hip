@@ -132,9 +132,13 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   // (CPW columns x NT/CPW row groups of RPT rows).
   const int n4 = e.width >> 2;
   const int n4_per = n4 / (int)gridDim.y, c4_base = (int)blockIdx.y * n4_per;
+  // (n4_per need not divide the 256 threads - width 768 gives 192: the NT % CPW surplus threads sit the column phase out)
   const int CPW = n4_per < NT ? n4_per : NT;
-  const int RPT = ER / (NT / CPW);
-  const int tc = t % CPW, r_first = (t / CPW) * RPT;
+  const int RG = NT / CPW;               // row groups
+  const int RPT = (ER + RG - 1) / RG;    // rows per group
+  const int tc = t % CPW, rg = t / CPW;
+  const int r_first = rg < RG ? rg * RPT : ER;
+  const int r_last = r_first + RPT < ER ? r_first + RPT : ER;
   floatx4 w0[IN], b0;
   {
     const int c4 = c4_base + tc;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     }
     if (e.ps.softflow != 0.0f) b += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft)[c4];
 #pragma unroll 4
-    for (int r = r_first; r < r_first + RPT; ++r) {
+    for (int r = r_first; r < r_last; ++r) {
       // the row's 16 inputs as four LDS broadcast reads (same address in every lane)
       float u[ROWBUF];
 #pragma unroll

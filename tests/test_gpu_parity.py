@@ -553,7 +553,9 @@ def test_cabi_status_codes_and_edge_sizes():
     from ikflow_amd.model import FlowLayout
 
     with pytest.raises(EngineError, match="coeff_fn_internal_size"):
-        Engine(FlowLayout(nb_nodes=2, dim=9, dim_cond=8, width=300, n_hidden=2, clamp=2.5, ndof=7), robot, DEV)
+        Engine(FlowLayout(nb_nodes=2, dim=9, dim_cond=8, width=5000, n_hidden=2, clamp=2.5, ndof=7), robot, DEV)
+    with pytest.raises(EngineError, match="n_layers"):
+        Engine(FlowLayout(nb_nodes=2, dim=9, dim_cond=8, width=256, n_hidden=5, clamp=2.5, ndof=7), robot, DEV)
 
 
 def test_hip_path_reproduces_committed_golden_fixtures():
