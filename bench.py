@@ -489,7 +489,7 @@ def main():
             name = MODEL_DESCRIPTIONS[args.model]["robot_name"]
             out["cpu_baseline"] = cpu_baseline(sd, layout, name, poses.cpu(), latent.cpu(), args.cpu_seconds)
             if not args.no_cells and not args.million:
-                out["cpu_baseline"]["exact_ik"] = cpu_baseline_exact(sd, layout, name, poses[:256].cpu(), out["cpu_baseline"]["cores"], 1e-3, 0.01)
+                out["cpu_baseline"]["exact_ik"] = cpu_baseline_exact(sd, layout, name, poses[:2048].cpu(), out["cpu_baseline"]["cores"], 1e-3, 0.01)
         print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist

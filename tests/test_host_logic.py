@@ -247,3 +247,71 @@ def test_bench_and_entry_contract_host_side(monkeypatch):
     import __graft_entry__ as ge
 
     assert callable(ge.build) and callable(ge.smoke)
+
+
+def test_verify_weights_tool_on_a_synthetic_pickle(tmp_path):
+    """tools/verify_weights.py on a pickle laid out like a released file: torch tensors, "nn_model." prefix
+    (scripts/download_model_from_wandb_checkpoint.py:13-28), M / M_inv / b / logDetM of module 0, perm + perm_inv."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import verify_weights as vw
+
+    robot, hp, lay, sd = panda_model(seed=2)
+    full = {"nn_model." + k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    full["nn_model.module_list.0.logDetM"] = torch.tensor(-6.1)
+    path = tmp_path / "panda__lyric-puddle-191__global_step%3D5.25M.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(full, f)
+    loaded = vw.load_any(str(path))
+    assert "module_list.0.M_inv" in loaded and all(not k.startswith("nn_model.") for k in loaded)
+    arch = vw.infer_architecture(loaded)
+    assert arch == dict(nb_nodes=12, dim=7, width=1024, n_hidden=3, dim_cond=8, sigmoid_on_output=False)
+    ok, rep = vw.check_structure(loaded, "panda__full__lp191_5.25m")
+    assert ok and rep["keys_and_shapes"] == "ok" and rep["permutations_equal_numpy_seed_i"] and rep["M_inv_diag_matches_joint_limits"]
+    assert rep["unknown_keys"] == [] and rep["f16x3_mode_usable"] and rep["layout"]["weight_bytes"] == 203440800
+    # a file whose permutation tables are not the seed-i ones is reported (and still loadable); a broken one fails
+    other = dict(loaded)
+    other["module_list.5.perm_inv"] = np.roll(other["module_list.5.perm_inv"], 1)
+    other["module_list.5.perm"] = np.argsort(other["module_list.5.perm_inv"])
+    ok2, rep2 = vw.check_structure(other, "panda__full__lp191_5.25m")
+    assert ok2 and rep2["permutation_blocks_differing"] == [2]
+    other["module_list.5.perm_inv"] = np.zeros(7, dtype=np.int64)
+    assert not vw.check_structure(other, "panda__full__lp191_5.25m")[0]
+    wrong = dict(loaded)
+    wrong["module_list.0.M_inv"] = wrong["module_list.0.M_inv"] * 2.0
+    assert not vw.check_structure(wrong, "panda__full__lp191_5.25m")[0]
+    assert not vw.check_structure(loaded, "fetch_arm__large__mh186_9.25m")[0]  # wrong architecture for the file
+    # the command line: structure fine, no GPU here -> exit 0 with the pose-error leg skipped
+    if not torch.cuda.is_available():
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "verify_weights.py"), str(path), "--model",
+                            "panda__full__lp191_5.25m"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "skipped: no GPU" in r.stdout
+
+
+def test_sigmoid_graph_requires_the_scaling_offset():
+    """module_list.0.b of the sigmoid_on_output graph is -slope * lo, never zero: a file without it is refused."""
+    from helpers import custom_model
+
+    robot, hp, _, sd = custom_model(nb_nodes=2, dim=9, n_hidden=2, width=256, softflow=False, sigmoid=True)
+    lay = layout_from(hp, robot)
+    validate_state_dict(lay, sd)
+    bad = {k: v for k, v in sd.items() if k != "module_list.0.b"}
+    with pytest.raises(RuntimeError, match="module_list.0.b"):
+        validate_state_dict(lay, bad)
+    plain_robot, plain_hp, _, plain_sd = tiny_model()
+    validate_state_dict(layout_from(plain_hp, plain_robot), {k: v for k, v in plain_sd.items() if k != "module_list.0.b"})  # optional there
+
+
+def test_kinematics_engine_cache_key_distinguishes_same_named_robots():
+    from ikflow_amd.engine import _robot_key
+    from ikflow_amd.robots import Joint, Robot
+
+    a, b = Panda(), Panda()
+    assert _robot_key(a) == _robot_key(b)
+    joints = list(a.joints)
+    j3 = joints[3]
+    joints[3] = Joint(j3.name, j3.kind, j3.origin_xyz, j3.origin_rpy, j3.axis, (-3.0, -0.1))  # edited limits, same name
+    assert _robot_key(Robot("panda", joints)) != _robot_key(a)
