@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libikflow_amd.so")
 SOURCES = ["flow_kernels.hip", "flow_fused.hip", "flow_split.hip", "kin_kernels.hip", "ikf_api.hip"]
-HEADERS = [os.path.join(CSRC, "ikf_internal.h"), os.path.join(_HERE, "..", "include", "ikflow_amd.h")]
+HEADERS = [os.path.join(CSRC, "ikf_internal.h"), os.path.join(CSRC, "flow_split_dma.inc"), os.path.join(_HERE, "..", "include", "ikflow_amd.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -53,7 +53,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + out)
         if verbose and out.strip():
             print(out)
-    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    # --no-undefined: a kernel template whose host stub was dropped must fail the build, not the first launch
+    link = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB_PATH] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + " ".join(link) + "\n" + r.stdout)

@@ -116,11 +116,12 @@ __device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, c
 // ---------------------------------------------------------------------------------------------------------------
 // subnet entry: pending coupling + first Linear + LeakyReLU for ER rows per workgroup
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int ER = 16;
-
-template <int IN>
-__global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
-  constexpr int NT = 256;
+// Geometry of a launch: NT threads per workgroup, ER rows per workgroup, column split gridDim.y.  More waves per CU hide
+// the LDS -> FMA -> store dependency chains of the first-Linear phase and let one workgroup's pending-coupling round trip
+// overlap another's stores (tools/gemm_probe.hip 300 sweeps the choices; profiles/r02_entry_sweep.txt).
+template <int IN, int NT, int ER>
+__global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
+  constexpr int UI = (ER * ROWBUF + NT - 1) / NT;  // (row, input column) items per thread
   __shared__ __attribute__((aligned(16))) float cat[ER * ROWBUF], U[ER * ROWBUF];  // U doubles as the slot-sum scratch
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * ER;
@@ -128,11 +129,11 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
   // this thread's slice of the first Linear (first column group) is fetched up front: its L2 latency hides behind the
   // pending-coupling phase below
   // Column split for small batches (gridDim.y workgroups share a row group, each redoing the cheap pending phase): the
-  // workgroup owns n4_per float4 column groups; when that is fewer than the 256 threads, the threads also split the rows
+  // workgroup owns n4_per float4 column groups; when that is fewer than the NT threads, the threads also split the rows
   // (CPW columns x NT/CPW row groups of RPT rows).
   const int n4 = e.width >> 2;
   const int n4_per = n4 / (int)gridDim.y, c4_base = (int)blockIdx.y * n4_per;
-  // (n4_per need not divide the 256 threads - width 768 gives 192: the NT % CPW surplus threads sit the column phase out)
+  // (n4_per need not divide the NT threads - width 768 gives 192: the NT % CPW surplus threads sit the column phase out)
   const int CPW = n4_per < NT ? n4_per : NT;
   const int RG = NT / CPW;               // row groups
   const int RPT = (ER + RG - 1) / RG;    // rows per group
@@ -146,25 +147,33 @@ __global__ __launch_bounds__(256) void k_subnet_entry(EntryArgs e) {
     for (int k = 0; k < IN; ++k) w0[k] = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width)[c4];
     b0 = reinterpret_cast<const floatx4*>(e.b1)[c4];
   }
-  // one thread per (row, column) of the 16-wide input row; the pose element is fetched before the pending phase
-  static_assert(ER * ROWBUF == NT, "entry kernel maps one thread to one (row, input column)");
-  const int ur = t / ROWBUF, uk = t % ROWBUF;
-  float pose_v = 0.f;
-  if (uk >= e.n_x && uk < IN) {
-    int gr = m0 + ur;
-    gr = gr < M ? gr : M - 1;
-    const long long grow = e.row0 + gr;
-    // one pose per row (n_mod == rows) and the single-pose broadcast (n_mod == 1) skip the 64-bit modulo
-    const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
-    const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
-    pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
+  // one item per (row, column) of the 16-wide input row; the pose element is fetched before the pending phase
+  float pose_v[UI];
+#pragma unroll
+  for (int it = 0; it < UI; ++it) {
+    const int idx = t + it * NT, ur = idx / ROWBUF, uk = idx % ROWBUF;
+    pose_v[it] = 0.f;
+    if (idx < ER * ROWBUF && uk >= e.n_x && uk < IN) {
+      int gr = m0 + ur;
+      gr = gr < M ? gr : M - 1;
+      const long long grow = e.row0 + gr;
+      // one pose per row (n_mod == rows) and the single-pose broadcast (n_mod == 1) skip the 64-bit modulo
+      const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
+      const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
+      pose_v[it] = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
+    }
   }
   IKF_TSTAMP(0)
   finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, cat, U, t);
   IKF_TSTAMP(1)
   // publish the new state and assemble u = [x_part, pose, 0-pad]
-  if (blockIdx.y == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
-  U[ur * ROWBUF + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;
+#pragma unroll
+  for (int it = 0; it < UI; ++it) {
+    const int idx = t + it * NT, ur = idx / ROWBUF, uk = idx % ROWBUF;
+    if (idx >= ER * ROWBUF) continue;
+    if (blockIdx.y == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
+    U[ur * ROWBUF + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v[it];
+  }
   __syncthreads();
   IKF_TSTAMP(2)
   for (int cc = tc; cc < n4_per; cc += CPW) {
@@ -566,6 +575,84 @@ constexpr size_t skinny_lds() {
              : sizeof(float) * 2 * KBM * (KBK + 4);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// tail of the small-batch kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.
+// Call after a barrier that ends every fragment read of the loop (smem is reused from its start).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool EPI_RED, int NH>
+__device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx16& acc, float* smem, int m0, int n0, int t,
+                                            int lane, int wave, int nh, int kq) {
+  constexpr int BM = KBM, BN = NH * 32, NT = NH * KKS * 64, KS = KKS;
+  constexpr int LDT = BN + 4;
+  const int N = g.N;
+  IKF_TSTAMP(40)
+
+  // ---- sum the k-slice partial blocks in fixed order kq = 0, 1, ..: every wave parks its block in LDS, then wave
+  // (kq, nh) finishes accumulator registers 2*kq and 2*kq+1 (two output rows per lane half) of column half nh
+  float* red = smem;  // [KS][NH][16][64]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[((kq * NH + nh) * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  float fin[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 2 * kq + j;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < KS; ++q) v += red[((q * NH + nh) * 16 + r) * 64 + lane];
+    v += g.bias[n0 + nh * 32 + col_l];
+    fin[j] = v > 0.f ? v : v * g.slope;
+  }
+  if constexpr (!EPI_RED) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * kq + j;
+      const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
+      g.C[(size_t)row * N + n0 + nh * 32 + col_l] = fin[j];  // row-padded buffer: unpredicated
+    }
+  } else {
+    float* T = smem + KS * NH * 16 * 64;  // behind red[] (other waves may still be summing)
+    float* Wl = T + BM * LDT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 2 * kq + j;
+      const int rl = (r & 3) + 8 * (r >> 2) + row_h;
+      T[rl * LDT + nh * 32 + col_l] = fin[j];
+    }
+    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
+      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      floatx4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
+    }
+    __syncthreads();
+    if (wave == 0) {  // one slot per tile (64 columns: same MFMA order as the large tiles; 32 columns: half slots)
+      floatx16 pacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+      const float* pa = Wl + (lane & 31) * LDT + (lane >> 5) * 4;
+      const float* pb = T + (lane & 31) * LDT + (lane >> 5) * 4;
+#pragma unroll
+      for (int ks = 0; ks < BN / 8; ++ks) {
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+      }
+      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2) + row_h;
+        pout[o] = pacc[r];
+      }
+    }
+  }
+  IKF_TSTAMP(41)
+}
+
 template <bool EPI_RED, int NH>
 __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArgs g) {
   constexpr int BM = KBM, BN = NH * 32, BK = KBK, NT = NH * KKS * 64, KS = KKS;
@@ -695,72 +782,7 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
 #undef IKK_LDA
 #undef IKK_LDW
   __syncthreads();  // all fragment reads done before the stage area is reused
-  IKF_TSTAMP(40)
-
-  // ---- sum the k-slice partial blocks in fixed order kq = 0, 1, ..: every wave parks its block in LDS, then wave
-  // (kq, nh) finishes accumulator registers 2*kq and 2*kq+1 (two output rows per lane half) of column half nh
-  float* red = smem;  // [KS][NH][16][64]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) red[((kq * NH + nh) * 16 + r) * 64 + lane] = acc[r];
-  __syncthreads();
-  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
-  float fin[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = 2 * kq + j;
-    float v = 0.f;
-#pragma unroll
-    for (int q = 0; q < KS; ++q) v += red[((q * NH + nh) * 16 + r) * 64 + lane];
-    v += g.bias[n0 + nh * 32 + col_l];
-    fin[j] = v > 0.f ? v : v * g.slope;
-  }
-  if constexpr (!EPI_RED) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = 2 * kq + j;
-      const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
-      g.C[(size_t)row * N + n0 + nh * 32 + col_l] = fin[j];  // row-padded buffer: unpredicated
-    }
-  } else {
-    float* T = smem + KS * NH * 16 * 64;  // behind red[] (other waves may still be summing)
-    float* Wl = T + BM * LDT;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = 2 * kq + j;
-      const int rl = (r & 3) + 8 * (r >> 2) + row_h;
-      T[rl * LDT + nh * 32 + col_l] = fin[j];
-    }
-    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
-      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
-      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
-    }
-    __syncthreads();
-    if (wave == 0) {  // one slot per tile (64 columns: same MFMA order as the large tiles; 32 columns: half slots)
-      floatx16 pacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-      const float* pa = Wl + (lane & 31) * LDT + (lane >> 5) * 4;
-      const float* pb = T + (lane & 31) * LDT + (lane >> 5) * 4;
-#pragma unroll
-      for (int ks = 0; ks < BN / 8; ++ks) {
-        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
-        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
-      }
-      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int o = (r & 3) + 8 * (r >> 2) + row_h;
-        pout[o] = pacc[r];
-      }
-    }
-  }
-  IKF_TSTAMP(41)
+  skinny_tail<EPI_RED, NH>(g, acc, smem, m0, n0, t, lane, wave, nh, kq);
 }
 
 // fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
@@ -863,25 +885,48 @@ hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipSt
   }
 }
 
+// entry-kernel geometry: {threads, rows per workgroup}
+int g_entry_geom_override = -1;  // probes: force a geometry (index into the table below)
+template <int IN>
+static hipError_t launch_entry_in(const EntryArgs& e, int geom, unsigned cs, hipStream_t s) {
+#define IKF_ENTRY_GEOM(G, NT_, ER_) \
+  case G: hipLaunchKernelGGL((k_subnet_entry<IN, NT_, ER_>), dim3((unsigned)((e.M + ER_ - 1) / ER_), cs), dim3(NT_), 0, s, e); break;
+  switch (geom) {
+    IKF_ENTRY_GEOM(0, 256, 16)
+    IKF_ENTRY_GEOM(1, 512, 16)
+    IKF_ENTRY_GEOM(2, 256, 8)
+    IKF_ENTRY_GEOM(3, 512, 32)
+    IKF_ENTRY_GEOM(4, 1024, 32)
+    IKF_ENTRY_GEOM(5, 512, 8)
+    default: return hipErrorInvalidValue;
+  }
+#undef IKF_ENTRY_GEOM
+  return hipGetLastError();
+}
+
 hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s) {
   if (e.M <= 0) return hipSuccess;
   if (e.D > ROWBUF || e.pend.n_out > ROWBUF || e.width % 4 != 0) return hipErrorInvalidValue;
-  const unsigned grid = (unsigned)((e.M + ER - 1) / ER);
   // up to 1024 rows (<= 64 row groups) four workgroups share a row group's columns: the launch is a latency chain
   // there and the first Linear of 16 rows x `width` is its longest link
   const int n4 = e.width / 4;
   unsigned cs = 1;
   if (e.M <= 1024 && n4 % 4 == 0 && n4 / 4 >= 64) cs = 4;
   else if (e.M <= 2048 && n4 % 2 == 0 && n4 / 2 >= 64) cs = 2;
-#define IKF_ENTRY_CASE(IN) \
-  case IN: hipLaunchKernelGGL((k_subnet_entry<IN>), dim3(grid, cs), dim3(256), 0, s, e); break;
+  // 512 threads: two waves per SIMD overlap one's LDS -> FMA -> store chains with the other's; 8-row workgroups at small
+  // batches double the workgroups in flight (tools/gemm_probe.hip 300: 8.6 -> 7.7 us at 4096 rows, 5.2 -> 4.9 at 512)
+  const int geom = g_entry_geom_override >= 0 ? g_entry_geom_override : (e.M <= 768 ? 5 : 1);
   switch (n_in) {
-    IKF_ENTRY_CASE(8) IKF_ENTRY_CASE(9) IKF_ENTRY_CASE(10) IKF_ENTRY_CASE(11)
-    IKF_ENTRY_CASE(12) IKF_ENTRY_CASE(13) IKF_ENTRY_CASE(14) IKF_ENTRY_CASE(15)
+    case 8: return launch_entry_in<8>(e, geom, cs, s);
+    case 9: return launch_entry_in<9>(e, geom, cs, s);
+    case 10: return launch_entry_in<10>(e, geom, cs, s);
+    case 11: return launch_entry_in<11>(e, geom, cs, s);
+    case 12: return launch_entry_in<12>(e, geom, cs, s);
+    case 13: return launch_entry_in<13>(e, geom, cs, s);
+    case 14: return launch_entry_in<14>(e, geom, cs, s);
+    case 15: return launch_entry_in<15>(e, geom, cs, s);
     default: return hipErrorInvalidValue;
   }
-#undef IKF_ENTRY_CASE
-  return hipGetLastError();
 }
 
 hipError_t launch_flow_finalize(const FinalizeArgs& f, hipStream_t s) {

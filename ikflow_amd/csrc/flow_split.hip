@@ -321,238 +321,31 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <bool EPI_RED>
-__global__ __launch_bounds__(256) void k_split_gemm_dma(SplitGemmArgs g) {
-  constexpr int BM = 128, BN = 128, NT = 256;
-  constexpr int MI = 2, NI = 2;
-  constexpr int LINE = 32;                 // dwords per line (128 B), unpadded
-  constexpr int STAGE = (BM + BN) * LINE;  // dwords per stage (32 KB)
-  constexpr int NST = 4;
-  constexpr int LDT = BN + 4;
-  static_assert(NST * STAGE >= (BM + 32) * LDT, "epilogue tile must fit in the stage area");
+#define IKD_WN 2
+#define IKD_KERNEL k_split_gemm_dma
+#include "flow_split_dma.inc"
+#undef IKD_WN
+#undef IKD_KERNEL
+#define IKD_WN 4
+#define IKD_KERNEL k_split_gemm_dma8
+#include "flow_split_dma.inc"
+#undef IKD_WN
+#undef IKD_KERNEL
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [4][BM + BN][32]
-
-  const int M = g.M, N = g.N, K = g.K;
-  const int tiles_n = N / BN;
-  const int nwg = gridDim.x;
-  int tile;
-  {
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-  }
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: LDS-DMA destinations go through M0
-  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-
-  floatx16 am[MI][NI], ac[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac[i][j][r] = 0.f; }
-
-  // DMA sources: this wave fills chunks c = wave + 4q (q = 0..7) of every stage; chunk c < 16 is A lines 8c..8c+7, else W
-  // lines 8(c-16)..; lane i of the instruction lands on line 8c + i/8, physical slot i%8 -> fetches logical slot
-  // (i%8) ^ ((line >> 1) & 7) of that line
-  // (buffer form: SGPR descriptor + loop-invariant 32-bit byte offset + scalar k offset; no 64-bit vector addresses)
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.A)), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(g.W)), 0, 0x7fffffff, 0x00020000);
-  unsigned doff[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int c = wave + 4 * q;
-    const int line = (c & 15) * 8 + (lane >> 3);          // tile-local line within its operand
-    const int ls = (lane & 7) ^ ((line >> 1) & 7);        // logical slot to fetch
-    if (q < 4) {                                          // c < 16  <=>  q < 4 (wave < 4)
-      int gr = m0 + line;
-      gr = gr < M ? gr : M - 1;
-      doff[q] = ((unsigned)gr * (unsigned)K + ls * 4) * 4u;
-    } else {
-      doff[q] = ((unsigned)(n0 + line) * (unsigned)K + ls * 4) * 4u;
-    }
-  }
-#define IKD_DMA1(q, kt_, st_)                                                                                      \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds((q) < 4 ? rsA : rsW, (lds_ptr_t)((st_) + (wave + 4 * (q)) * 256), 16, doff[q], \
-                                       __builtin_amdgcn_readfirstlane((kt_) * 128), 0, 0);
-  // fragment reads: line r = w? + 32 i + (lane & 31), logical slot plane*4 + step*2 + (lane >> 5), physical = logical ^ swz
-  const int swz = ((lane & 31) >> 1) & 7;
-  const int fragA = (wm + (lane & 31)) * LINE;
-  const int fragB = BM * LINE + (wn + (lane & 31)) * LINE;
-  const int hs = lane >> 5;
-  const int KT = K / 32;
-
-#define IKD_DMA(kt_)                                                                                               \
-  {                                                                                                               \
-    float* st_ = smem + ((kt_) & 3) * STAGE;                                                                      \
-    _Pragma("unroll") for (int q = 0; q < 8; ++q) IKD_DMA1(q, kt_, st_)                                           \
-  }
-#define IKD_FRAG(AH, AL, BH, BL, kt_, s_)                                                                          \
-  {                                                                                                               \
-    const float* sp_ = smem + ((kt_) & 3) * STAGE;                                                                \
-    const int ph_ = (((s_) * 2 + hs) ^ swz) * 4, pl_ = ((4 + (s_) * 2 + hs) ^ swz) * 4;                           \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-      AH[i] = *reinterpret_cast<const half8*>(sp_ + fragA + i * 32 * LINE + ph_);                                 \
-      AL[i] = *reinterpret_cast<const half8*>(sp_ + fragA + i * 32 * LINE + pl_);                                 \
-    }                                                                                                             \
-    _Pragma("unroll") for (int j = 0; j < NI; ++j) {                                                              \
-      BH[j] = *reinterpret_cast<const half8*>(sp_ + fragB + j * 32 * LINE + ph_);                                 \
-      BL[j] = *reinterpret_cast<const half8*>(sp_ + fragB + j * 32 * LINE + pl_);                                 \
-    }                                                                                                             \
-  }
-#define IKD_MFMA3(AH, AL, BH, BL)                                                                                  \
-  {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)                  \
-      am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], am[i][j], 0, 0, 0);                         \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)                  \
-      ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], ac[i][j], 0, 0, 0);                         \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j)                  \
-      ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], ac[i][j], 0, 0, 0);                         \
-  }
-
-  half8 ah0[MI], al0[MI], bh0[NI], bl0[NI], ah1[MI], al1[MI], bh1[NI], bl1[NI];
-  IKS_TSTAMP(0)
-  IKD_DMA(0)
-  if (KT > 1) IKD_DMA(1)
-  if (KT > 2) IKD_DMA(2)
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // tile 0 landed (this wave's share)
-  __builtin_amdgcn_s_barrier();
-  IKD_FRAG(ah0, al0, bh0, bl0, 0, 0)
-
-  IKS_TSTAMP(1)
-  for (int kt = 0; kt < KT; ++kt) {
-    IKD_FRAG(ah1, al1, bh1, bl1, kt, 1)
-    IKD_MFMA3(ah0, al0, bh0, bl0)
-#if !defined(IKD_PINS) || (IKD_PINS & 1)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {  // step-0 MFMAs shadow the step-1 fragment reads
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#endif
-    // own DMAs of tile kt+1 complete (tile kt+2's 8 may stay in flight), then every wave's
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    {  // prefetch three tiles ahead into the stage whose readers are all past this barrier (clamped near the end)
-      const int ktn = kt + 3 < KT ? kt + 3 : KT - 1;
-      float* st_ = smem + ((kt + 3) & 3) * STAGE;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) IKD_DMA1(q, ktn, st_)
-    }
-    IKD_FRAG(ah0, al0, bh0, bl0, kt + 1, 0)  // next tile's first step (harmless stale read after the last tile)
-    IKD_MFMA3(ah1, al1, bh1, bl1)
-#if !defined(IKD_PINS) || (IKD_PINS & 2)
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {  // step-1 MFMAs shadow the DMA issue and the next fragment reads
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (i < 8) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-    }
-#endif
-  }
-#undef IKD_DMA
-#undef IKD_DMA1
-#undef IKD_FRAG
-#undef IKD_MFMA3
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the clamped tail DMAs before the stage area is reused
-  __syncthreads();
-
-  // ---- epilogue (same as k_split_gemm)
-  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
-  float* T = smem;
-  constexpr float inv_scale = 1.0f / IKF_SPLIT_SCALE;
-#pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int cl = wn + j * 32 + col_l;
-    const float bv = g.bias[n0 + cl];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
-        float v = fmaf(ac[i][j][r], inv_scale, am[i][j][r]) + bv;
-        v = v > 0.f ? v : v * g.slope;
-        T[rl * LDT + cl] = v;
-      }
-    }
-  }
-  if constexpr (!EPI_RED) {
-    __syncthreads();
-    char* Cb = reinterpret_cast<char*>(g.C);
-    constexpr int CH = BN / 8;
-    bool range_bad = false;
-    for (int idx = t; idx < BM * CH; idx += NT) {
-      const int rl = idx / CH, ch = idx - rl * CH;
-      const floatx4 v0 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8);
-      const floatx4 v1 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8 + 4);
-      half8 hi, lo;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        hi[q] = (_Float16)v0[q];
-        lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
-        hi[4 + q] = (_Float16)v1[q];
-        lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
-        range_bad = range_bad || split_out_of_range(v0[q]) || split_out_of_range(v1[q]);
-      }
-      const int col = n0 + ch * 8;
-      char* p = Cb + (size_t)(m0 + rl) * N * 4 + (size_t)(col >> 5) * 128 + (col & 31) * 2;
-      *reinterpret_cast<half8*>(p) = hi;
-      *reinterpret_cast<half8*>(p + 64) = lo;
-    }
-    if (range_bad && g.flag) atomicOr(g.flag, 1);
-  } else {
-    float* Wl = smem + BM * LDT;
-    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
-      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
-      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
-    }
-    __syncthreads();
-    constexpr int RB = BM / 32, FKH = BN / 64, CW = 64;
-    for (int job = wave; job < RB * FKH; job += NT / 64) {
-      const int rb = job % RB, kh = job / RB;
-      floatx16 pacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-      const float* pa = Wl + (lane & 31) * LDT + kh * CW + (lane >> 5) * 4;
-      const float* pb = T + (rb * 32 + (lane & 31)) * LDT + kh * CW + (lane >> 5) * 4;
-#pragma unroll
-      for (int ks = 0; ks < CW / 8; ++ks) {
-        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
-        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
-      }
-      float* pout = g.P_out + (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int o = (r & 3) + 8 * (r >> 2) + row_h;
-        pout[o] = pacc[r];
-      }
-    }
-  }
-  IKS_TSTAMP(41)
-}
-
-template <bool EPI_RED>
-static hipError_t launch_sg_dma(const SplitGemmArgs& a, hipStream_t s) {
+int g_split_dma_waves_n = 4;  // waves along N of the LDS-DMA kernel: 4 = 8 waves (default: -24 % shader cycles, -7..10 % wall time - the chip clocks down under it), 2 = 4 waves; probes may flip it
+template <bool EPI_RED, int WN>
+static hipError_t launch_sg_dma_w(const SplitGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = (size_t)4 * 256 * 32 * sizeof(float);
-  auto kern = k_split_gemm_dma<EPI_RED>;
+  auto kern = WN == 4 ? k_split_gemm_dma8<EPI_RED> : k_split_gemm_dma<EPI_RED>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long grid = (((long long)a.M + 127) / 128) * (a.N / 128);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(2 * WN * 64), smem, s, a);
   return hipGetLastError();
+}
+template <bool EPI_RED>
+static hipError_t launch_sg_dma(const SplitGemmArgs& a, hipStream_t s) {
+  return g_split_dma_waves_n == 4 ? launch_sg_dma_w<EPI_RED, 4>(a, s) : launch_sg_dma_w<EPI_RED, 2>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

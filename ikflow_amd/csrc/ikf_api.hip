@@ -554,7 +554,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..104 fused)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -620,11 +620,11 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
     e.width = d.width; e.slope = d.slope; e.h_out = m->hA; e.split_out = split ? 1 : 0;
     e.split_flag = split ? m->d_split_flag : nullptr;
-    IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     FusedGemmArgs g{};
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
     const int n_mid = d.n_hidden - 1;
+    IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     float* cur = m->hA;
     float* nxt = m->hB;
     for (int l = 0; l < n_mid; ++l) {

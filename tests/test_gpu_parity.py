@@ -959,3 +959,4 @@ def test_one_handle_called_from_two_streams():
     for a, b in zip(want, got):
         assert torch.equal(a, b)
     assert torch.cuda.current_device() == 0
+

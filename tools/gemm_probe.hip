@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
     }
   }
   int vsel = argc > 3 ? atoi(argv[3]) : -1;
+  if (argc > 5) ikf::g_split_dma_waves_n = atoi(argv[5]);  // LDS-DMA f16-split kernel: 2 = 4 waves, 4 = 8 waves
   if (vsel == 300) {  // k_subnet_entry<11> timeline: pending coupling (16 slots) + first Linear, rows = M
     const int D = 7, W1 = 1024, IN = 11;
     float *x, *x2, *P, *w1t, *b1, *bl, *h; int* perm;
@@ -84,14 +85,20 @@ int main(int argc, char** argv) {
     e.x_src = x; e.x_dst = x2; e.M = M; e.D = D; e.L1 = 3; e.clamp = 2.5f; e.x_off = 0; e.n_x = 3;
     e.ps.poses = A; e.ps.idx = nullptr; e.ps.n_mod = M; e.ps.stride = 7; e.ps.softflow = 0.f; e.row0 = 0;
     e.w1t = w1t; e.w1soft = b1; e.b1 = b1; e.width = W1; e.slope = 0.01f; e.h_out = h; e.split_out = 0;
-    for (int rep = 0; rep < 3; ++rep) {
-      for (int i = 0; i < 10; ++i) ikf::launch_subnet_entry(IN - 0, e, 0);
-      CK(hipEventRecord(e0, 0));
-      for (int i = 0; i < iters; ++i) ikf::launch_subnet_entry(IN, e, 0);
-      CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
-      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-      printf("k_subnet_entry<11> M=%d: %.2f us/launch\n", M, 1000.0 * ms / iters);
+    for (int geom = 0; geom < 6; ++geom) {
+      ikf::g_entry_geom_override = geom;
+      float best = 1e9f;
+      for (int rep = 0; rep < 3; ++rep) {
+        for (int i = 0; i < 10; ++i) CK(ikf::launch_subnet_entry(IN - 0, e, 0));
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) ikf::launch_subnet_entry(IN, e, 0);
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fminf(best, 1000.0f * ms / iters);
+      }
+      printf("k_subnet_entry<11> M=%d geometry %d: %.2f us/launch\n", M, geom, best);
     }
+    ikf::g_entry_geom_override = argc > 4 ? atoi(argv[4]) : 0;
     unsigned long long* tb; const int nb = 4096;
     CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
