@@ -176,6 +176,16 @@ class Robot:
         self._collision_model = (folded, pairs)
         return self
 
+    def use_approximate_collision_model(self):
+        """Attach this repository's own approximate capsule model (Panda only; see PANDA_APPROX_CAPSULES - not jrl's
+        geometry, no parity claim).  Capsule pairs on adjacent moving frames are skipped as well as the listed ones."""
+        if self._name != "panda":
+            raise ValueError(f"no approximate capsule model ships for '{self._name}' (only for 'panda')")
+        self.set_collision_capsules(PANDA_APPROX_CAPSULES, PANDA_APPROX_IGNORED)
+        folded, pairs = self._collision_model
+        self._collision_model = (folded, [(a, b) for a, b in pairs if abs(folded[a][0] - folded[b][0]) > 1])
+        return self
+
     @property
     def has_collision_model(self) -> bool:
         return getattr(self, "_collision_model", None) is not None
@@ -225,6 +235,30 @@ def Panda() -> Robot:
             Joint("panda_hand_joint", JOINT_FIXED, (0.0, 0.0, 0.0), (0.0, 0.0, -math.pi / 4.0)),
         ],
     )
+
+
+# An APPROXIMATE capsule model of the Panda, written for this repository from the public link dimensions (segments along
+# the link bodies between successive joint origins, radii of the link housings).  It is NOT jrl's capsule table and NOT the
+# Klampt mesh check the reference runs (ikflow/evaluation_utils.py:115-126): flags produced with it are an engineering
+# estimate, good for filtering gross self-intersections, and carry no parity claim.  (after_joint, p0, p1, radius) in the
+# child-link frame of `after_joint`; None = base link.
+PANDA_APPROX_CAPSULES = [
+    (None, (0.0, 0.0, 0.0), (0.0, 0.0, 0.14), 0.09),                    # 0  link0: base column
+    ("panda_joint1", (0.0, 0.0, -0.19), (0.0, 0.0, -0.03), 0.07),        # 1  link1: shoulder column
+    ("panda_joint2", (0.0, 0.0, -0.06), (0.0, 0.0, 0.06), 0.07),         # 2  link2: shoulder housing (along the joint axis)
+    ("panda_joint2", (0.0, -0.07, 0.0), (0.0, -0.14, 0.0), 0.065),       # 3  link2: lower upper-arm
+    ("panda_joint3", (0.0, 0.0, -0.16), (0.0, 0.0, -0.03), 0.065),       # 4  link3: upper upper-arm
+    ("panda_joint4", (0.0, 0.0, -0.06), (0.0, 0.0, 0.06), 0.065),        # 5  link4: elbow housing (along the joint axis)
+    ("panda_joint4", (-0.0825, 0.07, 0.0), (-0.0825, 0.13, 0.0), 0.06),  # 6  link4: lower forearm
+    ("panda_joint5", (0.0, 0.0, -0.24), (0.0, 0.0, -0.07), 0.06),        # 7  link5: forearm
+    ("panda_joint6", (0.0, 0.0, 0.0), (0.088, 0.0, 0.0), 0.05),          # 8  link6: wrist
+    ("panda_joint7", (0.0, 0.0, 0.02), (0.0, 0.0, 0.09), 0.045),         # 9  link7: flange
+    ("panda_hand_joint", (0.0, -0.07, 0.025), (0.0, 0.07, 0.025), 0.035),  # 10 hand body
+    ("panda_hand_joint", (0.0, 0.0, 0.06), (0.0, 0.0, 0.10), 0.03),      # 11 fingers
+]
+# pairs never tested besides capsules on the same or on adjacent moving frames (skipped automatically below): housings
+# that sit on coincident joint origins two frames apart
+PANDA_APPROX_IGNORED = [(1, 3), (2, 4), (5, 7), (6, 8), (7, 9), (7, 10), (8, 10), (8, 11)]
 
 
 def _fetch_arm_joints() -> List[Joint]:

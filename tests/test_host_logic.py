@@ -315,3 +315,14 @@ def test_kinematics_engine_cache_key_distinguishes_same_named_robots():
     j3 = joints[3]
     joints[3] = Joint(j3.name, j3.kind, j3.origin_xyz, j3.origin_rpy, j3.axis, (-3.0, -0.1))  # edited limits, same name
     assert _robot_key(Robot("panda", joints)) != _robot_key(a)
+
+
+def test_approximate_panda_capsule_model_host_side():
+    from ikflow_amd.robots import PANDA_APPROX_CAPSULES
+
+    robot = Panda().use_approximate_collision_model()
+    folded, pairs = robot._collision_model
+    assert len(folded) == len(PANDA_APPROX_CAPSULES) == 12 and [f[0] for f in folded] == [0, 1, 2, 2, 3, 4, 4, 5, 6, 7, 7, 7]
+    assert all(abs(folded[a][0] - folded[b][0]) > 1 for a, b in pairs) and len(pairs) == 45
+    with pytest.raises(ValueError, match="only for 'panda'"):
+        FetchArm().use_approximate_collision_model()
