@@ -991,3 +991,33 @@ def test_panda_approximate_capsule_model():
     det = s.generate_ik_solutions(robot.forward_kinematics(q[:40].to(DEV)), latent=latents(40, lay.dim, 3).to(DEV), return_detailed=True)
     assert det[4] is not None and det[4].dtype == torch.bool and det[4].shape == (40,)
     assert not Panda().has_collision_model  # opt-in: the default robot still answers None in the self-collision slot
+
+
+def test_softflow_scale_and_zero_row_calls():
+    """The 8th conditional entry (softflow scale; always 0.0 at inference in the reference, ikflow_solver.py:335-338) is a
+    C-ABI argument: a non-zero value must equal the oracle run on the full 8-entry conditional.  Plus the n = 0 forms of
+    every entry point."""
+    robot, hp, lay, sd = tiny_model(seed=6, gain=1.5)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 300
+    _, poses = reachable_poses(robot, n, 17)
+    lat = latents(n, lay.dim, 18)
+    for scale in (0.0, 0.37, -1.2):
+        cond = torch.cat([poses, torch.full((n, 1), scale)], dim=1)
+        ref = fo.run_inference_torch(sd, lay, robot, lat, cond, True)
+        got = eng.generate_approx(poses.to(DEV), lat.to(DEV), True, softflow_scale=scale).cpu()
+        assert (got - ref).abs().max().item() <= FLOW_TOL, scale
+    eng.set_gemm_variant(4)  # the unfused pipeline reads the softflow column too
+    cond = torch.cat([poses, torch.full((n, 1), 0.37)], dim=1)
+    got = eng.generate_approx(poses.to(DEV), lat.to(DEV), True, softflow_scale=0.37).cpu()
+    assert (got - fo.run_inference_torch(sd, lay, robot, lat, cond, True)).abs().max().item() <= FLOW_TOL
+    eng.set_gemm_variant(-1)
+    empty_q = torch.zeros(0, 7, device=DEV)
+    empty_p = torch.zeros(0, 7, device=DEV)
+    assert eng.forward_kinematics(empty_q).shape == (0, 7) and eng.lm_step(empty_p, empty_q).shape == (0, 7)
+    assert eng.pose_error(empty_q, empty_p)[0].shape == (0,) and eng.joint_limits_exceeded(empty_q).shape == (0,)
+    sol, valid = eng.refine_exact(empty_p, empty_q, 3, 1e-3, 0.1)
+    assert sol.shape == (0, 7) and valid.shape == (0,)
+    sol, valid = eng.generate_exact(empty_p, (1, 3), 1e-3, 0.1, seed_fn=lambda r, idx, rep: empty_q)
+    assert sol.shape == (0, 7) and valid.shape == (0,)
