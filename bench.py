@@ -57,6 +57,10 @@ def parse():
                    help="BASELINE config 5: 1,000,000 target poses per step sharded over the ranks (batch = 1e6 / world), "
                         "one all-gather per step (strong scaling)")
     p.add_argument("--dist-dry-run", action="store_true", help="tests only: gloo + CPU tensors + a stand-in for the engine")
+    p.add_argument("--no-live-pmc", action="store_true",
+                   help="do not measure roofline.traffic in this run (default at N=1: two rocprofv3 --pmc passes - FETCH_SIZE, WRITE_SIZE - "
+                        "over a 4-step sub-run of the headline workload, ~10 s; the committed PMC summary is reported beside it and is the "
+                        "fallback when rocprofv3 is not usable)")
     return p.parse_args()
 
 
@@ -215,6 +219,64 @@ def pmc_traffic_per_launch():
             return json.load(f).get("dominant_kernel_traffic_bytes_per_launch"), os.path.basename(files[-1])
     except Exception:
         return None, None
+
+
+def live_profile(kernel_substr="k_flow_gemm<"):
+    """Profiler figures of the dominant kernel measured in THIS run, by three rocprofv3 passes over a 4-step sub-run of the same
+    workload (child processes of this script, after the timed region):
+      --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes: the TCC block cannot hold both) -> HBM bytes per launch with the
+        guide's gfx950 correction (FETCH_SIZE counts half the bytes of wide coalesced reads; both counters are KiB);
+      --kernel-trace --stats -> average launch duration.
+    Returns {"traffic": bytes | None, "avg_us": float | None, "note": str}; never raises."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    out = {"traffic": None, "avg_us": None, "note": ""}
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        out["note"] = "rocprofv3 not found"
+        return out
+    sub = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-split-extra",
+           "--no-cells", "--no-live-pmc"]
+
+    def run(flags, steps="3", warmup="1"):
+        d = tempfile.mkdtemp(prefix="ikf_prof_", dir="/tmp")
+        sub[3], sub[5] = steps, warmup
+        subprocess.run([exe] + flags + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + sub, cwd="/tmp",
+                       env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+        return d
+
+    per_counter = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = run(["--pmc", counter, "--kernel-trace"])
+            try:
+                per_dispatch = {}
+                for r in csv.DictReader(open(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0])):
+                    if kernel_substr in r["Kernel_Name"] and "skinny" not in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+                per_counter[counter] = sum(per_dispatch.values()) / max(len(per_dispatch), 1) * 1024.0
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        out["traffic"] = int(2 * per_counter["FETCH_SIZE"] + per_counter["WRITE_SIZE"])
+        d = run(["--kernel-trace", "--stats"], steps="20", warmup="5")  # 1200 launches, like tools/profile_round.sh
+        try:
+            calls, total = 0, 0.0
+            for r in csv.DictReader(open(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0])):
+                if kernel_substr in r["Name"] and "skinny" not in r["Name"]:
+                    calls += int(r["Calls"])
+                    total += float(r["TotalDurationNs"])
+            out["avg_us"] = total / calls / 1e3 if calls else None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        out["note"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; traffic = 2 x FETCH_SIZE + "
+                       "WRITE_SIZE) over a 4-step sub-run and --kernel-trace --stats over a 25-step sub-run of the same workload")
+    except Exception as e:  # never let the profiler leg take the bench line down
+        out["note"] = f"rocprofv3 leg failed ({type(e).__name__}); committed profile figures reported instead"
+    return out
 
 
 def rocprof_kernel_avg_us(kernel_substr="k_flow_gemm<"):
@@ -421,6 +483,12 @@ def main():
     headline_cfg = args.batch == 4096 and args.model == MODEL and args.precision == "f32"
     traffic, traffic_src = pmc_traffic_per_launch() if headline_cfg else (None, None)
     prof_us, prof_src = rocprof_kernel_avg_us() if headline_cfg else (None, None)
+    live = {"traffic": None, "avg_us": None, "note": "not run"}
+    if not args.no_live_pmc and headline_cfg and world == 1:
+        live = live_profile()
+    live_traffic, live_note = live["traffic"], live["note"]
+    if live["avg_us"] is not None:
+        prof_us, prof_src = live["avg_us"], "rocprofv3 --kernel-trace --stats in this run"
     extra = {"flow_tflops_per_gpu": round(flow_tflops, 2), "frac_of_fp32_mfma_peak_end_to_end": round(flow_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
              "gemm_ms": round(gemm_ms, 5), "gemm_launches_per_step": gemm_layers}
     if args.precision == "f32" and not args.no_split_extra:
@@ -472,8 +540,11 @@ def main():
                                + (" (1,000,000 poses per step over all ranks)" if args.million else ""),
                    "global_batch": world * B, "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "HBM bytes per launch",
-                     "traffic_source": traffic_src, "kernel": eng.dominant_kernel_name(),
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": live_traffic if live_traffic is not None else traffic,
+                     "traffic_unit": "HBM bytes per launch",
+                     "traffic_source": live_note if live_traffic is not None else traffic_src,
+                     "traffic_committed": traffic, "traffic_committed_source": traffic_src, "traffic_live_note": live_note,
+                     "kernel": eng.dominant_kernel_name(),
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms,
                      "timing": f"hipEvent pair per launch on the engine stream, {n_launch} launches over extra steps; an empty pair "
                                f"({eng.last_event_overhead_ms * 1e3:.2f} us, calibrated on the same stream) is subtracted",

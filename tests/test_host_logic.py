@@ -237,7 +237,7 @@ def test_bench_and_entry_contract_host_side(monkeypatch):
 
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert (a.gpus, a.batch, a.precision, a.million, a.no_cells, a.dist_dry_run) == (1, 4096, "f32", False, False, False)
+    assert (a.gpus, a.batch, a.precision, a.million, a.no_cells, a.dist_dry_run, a.no_live_pmc) == (1, 4096, "f32", False, False, False, False)
     assert 0 < a.warmup < a.steps <= 100
     us, src = bench.rocprof_kernel_avg_us()
     assert 40.0 < us < 90.0 and src.endswith("_bench_kernel_stats.csv")

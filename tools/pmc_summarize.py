@@ -31,7 +31,7 @@ if dom:
     n = sum(kernels[k]["dispatches"] for k in dom)
     traffic = int(sum((kernels[k]["hbm_read_bytes_corrected"] + kernels[k].get("hbm_write_bytes", 0)) * kernels[k]["dispatches"] for k in dom) / n)
 json.dump({
-    "command": "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-extra --no-cells  (separate passes: FETCH_SIZE | WRITE_SIZE | SQ/GRBM set; see tools/profile_round.sh)",
+    "command": "cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc <COUNTERS> --kernel-trace --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-extra --no-cells --no-live-pmc  (separate passes: FETCH_SIZE | WRITE_SIZE | SQ/GRBM set; see tools/profile_round.sh)",
     "notes": "FETCH_SIZE/WRITE_SIZE are KiB per dispatch; gfx950 correction: hbm_read_bytes = 2*FETCH_SIZE*1024 (MI355X_MICROARCH.md, HBM section). The read figure includes Infinity-Cache hits (each of the 8 XCD L2s fetches the whole 4.2 MB weight matrix). SQ counters are summed over the chip.",
     "dominant_kernel": dom,
     "dominant_kernel_traffic_bytes_per_launch": traffic,

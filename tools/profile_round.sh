@@ -8,15 +8,15 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra --no-cells"
+BENCH="python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra --no-cells --no-live-pmc"
 rocprofv3 --kernel-trace --stats -d /tmp/kt_$R -o kt --output-format csv -- $BENCH > "$OUT/kt.log" 2>&1
 cp "$(find /tmp/kt_$R -name '*kernel_stats.csv' | head -1)" "$OUT/bench_kernel_stats.csv"
 for V in "b512:--batch 512" "f16x3:--precision f16x3" "b128:--batch 128"; do
   TAG=${V%%:*}; FLAGS=${V#*:}
-  rocprofv3 --kernel-trace --stats -d /tmp/kt_${R}_$TAG -o kt --output-format csv -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra --no-cells $FLAGS > "$OUT/kt_$TAG.log" 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/kt_${R}_$TAG -o kt --output-format csv -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra --no-cells --no-live-pmc $FLAGS > "$OUT/kt_$TAG.log" 2>&1
   cp "$(find /tmp/kt_${R}_$TAG -name '*kernel_stats.csv' | head -1)" "$OUT/bench_${TAG}_kernel_stats.csv"
 done
-SHORT="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-extra --no-cells"
+SHORT="python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split-extra --no-cells --no-live-pmc"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   i=$((i+1))
@@ -33,5 +33,5 @@ done
 cd "$REPO"
 mkdir -p profiles && cp "$OUT/pmc_summary.json" "profiles/${R}_pmc_summary.json"   # so the bench below reports this traffic
 python bench.py > "$OUT/bench_default.log" 2>&1; tail -1 "$OUT/bench_default.log" > "$OUT/bench_default.json"
-python bench.py --precision f16x3 --no-cpu-baseline --no-split-extra --no-cells 2>&1 | tail -1 > "$OUT/bench_f16x3.json"
+python bench.py --precision f16x3 --no-cpu-baseline --no-split-extra --no-cells --no-live-pmc 2>&1 | tail -1 > "$OUT/bench_f16x3.json"
 echo "profile_round: done -> $OUT"; ls -la "$OUT"
