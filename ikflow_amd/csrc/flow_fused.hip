@@ -785,6 +785,213 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
   skinny_tail<EPI_RED, NH>(g, acc, smem, m0, n0, t, lane, wave, nh, kq);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small batches, first hidden contraction of a subnet: k_subnet_entry and k_flow_gemm_skinny in ONE launch.
+// A launch at <= 512 rows is a latency chain (73 dependent launches, each ~ one memory round trip + its K loop + a
+// kernel boundary); this form removes one launch per subnet, the first-Linear round trip through HBM and every barrier of
+// the K loop:
+//   * every workgroup of a row tile (32 rows x NH*32 columns) finishes the pending coupling of ITS 32 rows (the cheap
+//     phase the column-split entry kernel already repeats per workgroup) and evaluates the whole first Linear + LeakyReLU
+//     of those rows - [32 x 16] . [16 x K] - ON THE MATRIX PIPE straight into LDS (A_full[32][K + 4], 131.6 KB at
+//     K = 1024): K/32 column blocks x 8 MFMAs, 4096 cycles per SIMD.  (On the VALU the same 360 k FMA per workgroup cost
+//     14 k cycles - measured, r02 - because the 16 column-tile workgroups of a row tile all repeat them.)  The accumulator
+//     starts from the bias and k runs upward inside and across the MFMAs, so the result is the entry kernel's fmaf chain;
+//   * the K loop reads its A fragments from that resident tile: no A loads, no LDS stage writes, no barrier per stage;
+//     the W-fragment stream of the first two k tiles and the first-Linear weights are requested before the pending phase;
+//   * workgroups with tn == 0 publish the new flow state.
+// Needs K <= 1024 (LDS), K/32 divisible by the wave count, and <= 256 tiles (one workgroup per CU).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int EG_ROWS = 32;
+constexpr int EG_ULD = ROWBUF + 1;  // row stride of the subnet-input tile (17: a column read across 32 rows is conflict-free)
+constexpr size_t entry_gemm_lds(int K) { return sizeof(float) * ((size_t)EG_ROWS * (K + 4) + 2 * EG_ROWS * ROWBUF + EG_ROWS * EG_ULD); }
+
+template <bool EPI_RED, int NH>
+__global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e, FusedGemmArgs g, int n_in) {
+  constexpr int BN = NH * 32, BK = KBK, NT = NH * KKS * 64, NW = NH * KKS;
+  constexpr int R = EG_ROWS;
+  constexpr int BPW_MAX = 32 / NW;  // first-Linear column blocks per wave at K = 1024 (2 with 16 waves, 4 with 8)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = g.K, N = g.N;
+  const int LDKF = K + 4;
+  float* A_full = smem;                    // [R][K + 4]; reused by skinny_tail after the loop
+  float* cat = smem + (size_t)R * LDKF;    // [R][ROWBUF]
+  float* sums = cat + R * ROWBUF;          // [R][ROWBUF] slot-sum scratch
+  float* U = sums + R * ROWBUF;            // [R][EG_ULD] the subnet input rows [x_part, pose, 0...]
+
+  const int tiles_n = N / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * R, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int nh = wave % NH, kq = wave / NH;
+  const int M = e.M, D = e.D;
+
+  // ---- pending coupling, load half: this thread's state element and the partial-sum slots of its (row, output) - issued
+  // FIRST so that the wait in front of their use does not also wait for the operand prefetches queued behind them (VMEM
+  // returns in order).  One item per thread (R * ROWBUF = 512 <= NT); <= 32 slots for every small-batch tile at K <= 1024.
+  const PendingCoupling& pc = e.pend;
+  const int p_nl = (pc.which == 1) ? D - e.L1 : e.L1;
+  const int p_off = (pc.which == 1) ? e.L1 : 0;
+  const int pr = t / ROWBUF, pd = t % ROWBUF;  // (row, state element / subnet output) of this thread
+  float p_xv = 0.f, p_a[32], p_b = 0.f;
+  {
+    int gr = m0 + pr;
+    gr = gr < M ? gr : M - 1;
+    if (t < R * ROWBUF && pd < D) p_xv = e.x_src[(size_t)gr * D + pd];
+    const bool has_sum = pc.P != nullptr && t < R * ROWBUF && pd < 2 * p_nl;
+    const float* p = pc.P ? pc.P + (size_t)(m0 + pr) * IKF_PSTRIDE + pd : nullptr;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) p_a[q] = (has_sum && q < pc.slots) ? p[(size_t)q * pc.slot_stride] : 0.f;
+    if (has_sum) p_b = pc.b_last[pd];
+  }
+
+  // ---- W fragments of k tiles 0 and 1 of the contraction (independent of everything below)
+  constexpr int WTILE = KKS * KKG * 256;
+  const int KT = K / BK;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
+  const unsigned wtile0 = (unsigned)(tn * NH + nh) * KT;
+  const unsigned woff = (unsigned)(kq * (KKG * 256) * 4) + lane * 16u;
+#define IKE_LDW(kk, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, woff + (kk) * 1024, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
+  floatx4 w0[KKG], w1[KKG];
+#pragma unroll
+  for (int kk = 0; kk < KKG; ++kk) w0[kk] = IKE_LDW(kk, 0);
+  {
+    const int k1 = KT > 1 ? 1 : 0;
+#pragma unroll
+    for (int kk = 0; kk < KKG; ++kk) w1[kk] = IKE_LDW(kk, k1);
+  }
+
+  // ---- first-Linear operands of this wave's column blocks.  The product is taken transposed - MFMA "A" operand = W1^T
+  // (lane % 32 = output column of the block), "B" operand = the input rows (lane % 32 = row) - so that a lane's accumulator
+  // registers 4q .. 4q+3 are four CONSECUTIVE columns of one row: the tile goes to LDS as 16-byte stores
+  const int bpw = (K / 32) / NW;  // column blocks per wave (launcher: divides, <= BPW_MAX)
+  const int hs = lane >> 5, cl = lane & 31;
+  float wb[BPW_MAX][8];
+  floatx4 bias4[BPW_MAX][4];
+#pragma unroll
+  for (int i = 0; i < BPW_MAX; ++i) {
+    const int cb = i < bpw ? wave * bpw + i : 0;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int k = 2 * s8 + hs;
+      const float v = e.w1t[(size_t)(k < n_in ? k : 0) * e.width + cb * 32 + cl];
+      wb[i][s8] = k < n_in ? v : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // accumulator register 4q + j  <->  column 8q + 4*hs + j of the block
+      floatx4 bv = *reinterpret_cast<const floatx4*>(e.b1 + cb * 32 + 8 * q + 4 * hs);
+      if (e.ps.softflow != 0.0f) bv += e.ps.softflow * *reinterpret_cast<const floatx4*>(e.w1soft + cb * 32 + 8 * q + 4 * hs);
+      bias4[i][q] = bv;
+    }
+  }
+
+  // ---- pose element of this thread's (row, input column) item, requested before the pending phase
+  const int ur = t / ROWBUF, uk = t % ROWBUF;
+  float pose_v = 0.f;
+  if (t < R * ROWBUF && uk >= e.n_x && uk < n_in) {
+    int gr = m0 + ur;
+    gr = gr < M ? gr : M - 1;
+    const long long grow = e.row0 + gr;
+    const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
+    const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
+    pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
+  }
+  IKF_TSTAMP(0)
+  // ---- pending coupling, compute half (same order of operations as finish_pending_rows: bias, slot 0, slot 1, ...)
+  if (pc.P != nullptr) {
+    if (t < R * ROWBUF && pd < 2 * p_nl) {
+      float sv = p_b;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) sv += p_a[q];
+      sums[pr * ROWBUF + pd] = sv;
+    }
+    __syncthreads();
+  }
+  if (t < R * ROWBUF && pd < D) {
+    float v = p_xv;
+    if (pc.P != nullptr && pd >= p_off && pd < p_off + p_nl) {
+      const int j = pd - p_off;
+      const float s_cl = e.clamp * (0.636f * atanf(sums[pr * ROWBUF + j]));
+      v = (v - sums[pr * ROWBUF + p_nl + j]) * expf(-s_cl);
+    }
+    cat[pr * ROWBUF + pd] = v;
+  }
+  __syncthreads();
+  IKF_TSTAMP(1)
+  if (t < R * ROWBUF) {
+    if (tn == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
+    U[ur * EG_ULD + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;  // 0 beyond n_in
+  }
+  __syncthreads();
+
+  // ---- first Linear + LeakyReLU of the 32 rows on the matrix pipe -> A_full
+  {
+    float ua[8];  // "B" fragment of step s: U[row = lane % 32][k = 2s + lane / 32]
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) ua[s8] = U[cl * EG_ULD + 2 * s8 + hs];
+#pragma unroll
+    for (int i = 0; i < BPW_MAX; ++i) {
+      if (i < bpw) {
+        floatx16 a1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a1[4 * q + 0] = bias4[i][q].x; a1[4 * q + 1] = bias4[i][q].y; a1[4 * q + 2] = bias4[i][q].z; a1[4 * q + 3] = bias4[i][q].w;
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+          if (2 * s8 < n_in) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i][s8], ua[s8], a1, 0, 0, 0);  // steps past n_in add 0 * 0
+        float* dst = A_full + (size_t)cl * LDKF + (wave * bpw + i) * 32 + 4 * hs;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          floatx4 v = {a1[4 * q + 0], a1[4 * q + 1], a1[4 * q + 2], a1[4 * q + 3]};
+          v.x = v.x > 0.f ? v.x : v.x * e.slope;
+          v.y = v.y > 0.f ? v.y : v.y * e.slope;
+          v.z = v.z > 0.f ? v.z : v.z * e.slope;
+          v.w = v.w > 0.f ? v.w : v.w * e.slope;
+          *reinterpret_cast<floatx4*>(dst + 8 * q) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  IKF_TSTAMP(2)
+
+  // ---- K loop: A fragments from the resident tile, W fragments streamed two tiles ahead; no barriers
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* fragA = A_full + (size_t)cl * LDKF + kq * KKW + hs * 4;
+#define IKE_MFMA(FA, FB)                                                                  \
+  {                                                                                       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.x, FB.x, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.y, FB.y, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.z, FB.z, acc, 0, 0, 0);                 \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.w, FB.w, acc, 0, 0, 0);                 \
+  }
+#define IKE_ITER(WC)                                                                      \
+  {                                                                                       \
+    const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;                                       \
+    const floatx4 fa0 = *reinterpret_cast<const floatx4*>(fragA + kt * BK);               \
+    const floatx4 fa1 = *reinterpret_cast<const floatx4*>(fragA + kt * BK + 8);           \
+    IKE_MFMA(fa0, WC[0])                                                                  \
+    WC[0] = IKE_LDW(0, k2);                                                               \
+    IKE_MFMA(fa1, WC[1])                                                                  \
+    WC[1] = IKE_LDW(1, k2);                                                               \
+    ++kt;                                                                                 \
+  }
+  static_assert(KKG == 2, "two MFMA groups per wave per k tile");
+  for (int kt = 0; kt < KT;) {  // KT is even (launcher: K % (2*BK) == 0)
+    IKE_ITER(w0)
+    IKE_ITER(w1)
+  }
+#undef IKE_ITER
+#undef IKE_MFMA
+#undef IKE_LDW
+  __syncthreads();  // every wave is done with A_full before the tail reuses the memory
+  IKF_TSTAMP(3)
+  skinny_tail<EPI_RED, NH>(g, acc, smem, m0, n0, t, lane, wave, nh, kq);
+}
+
 // fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
 //   (((tn32*KT + kt)*KKS + kq)*KKG + kk)*64 + lane  <-  W[tn32*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
 // (per 32-column tile and k tile: 8 k-slices x 2 MFMA groups x 64 lanes; a wave's fetch for one stage is 2 KB contiguous)
@@ -818,6 +1025,37 @@ static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
   const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a);
   return hipGetLastError();
+}
+
+template <bool EPI_RED, int NH>
+static hipError_t launch_entry_gemm_t(const EntryArgs& e, const FusedGemmArgs& a, int n_in, hipStream_t s) {
+  const size_t tail = skinny_lds<NH>();
+  size_t smem = entry_gemm_lds(a.K);
+  if (smem < tail) smem = tail;
+  auto kern = k_entry_gemm_skinny<EPI_RED, NH>;
+  static bool lds_ok[64] = {};
+  if (hipError_t err = ensure_dynamic_lds(kern, (size_t)160 * 1024, lds_ok); err != hipSuccess) return err;
+  const long long grid = (((long long)a.M + EG_ROWS - 1) / EG_ROWS) * (a.N / (NH * 32));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, e, a, n_in);
+  return hipGetLastError();
+}
+
+// true when the first hidden contraction of a subnet can run as k_entry_gemm_skinny for this batch
+bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out) {
+  if (cfg != 4 && cfg != 6) return false;  // kSkinnyCfg / kSkinny32Cfg
+  const int NH = cfg == 4 ? 2 : 1;
+  const int NW = NH * KKS;
+  const long long tiles = ((rows + EG_ROWS - 1) / EG_ROWS) * (width / (NH * 32));
+  return tiles <= 256 && width <= 1024 && width % (2 * KBK) == 0 && (width / 32) % NW == 0 && D <= ROWBUF && n_out <= ROWBUF;
+}
+
+hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e, const FusedGemmArgs& a, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (!entry_gemm_ok(cfg, a.M, a.N, e.D, e.pend.n_out) || a.K != a.N || a.Wf == nullptr || a.n_out > 16 || n_in > ROWBUF - 1 ||
+      e.width != a.K)
+    return hipErrorInvalidValue;
+  if (cfg == 4) return epi_red ? launch_entry_gemm_t<true, 2>(e, a, n_in, s) : launch_entry_gemm_t<false, 2>(e, a, n_in, s);
+  return epi_red ? launch_entry_gemm_t<true, 1>(e, a, n_in, s) : launch_entry_gemm_t<false, 1>(e, a, n_in, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

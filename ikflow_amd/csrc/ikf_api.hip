@@ -58,6 +58,7 @@ struct ikf_model {
   bool loaded = false;
   int gemm_variant = -1;  // -1 = choose by batch size
   int tile_cfg = -1;      // fused pipeline: -1 = choose by batch size, 0..3 forced (variant 100..103)
+  int fuse_entry = 1;     // small batches: entry kernel + first hidden contraction as one launch (0: always two launches)
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
   uint16_t* split_arena = nullptr;  // split-32 images of the hidden Linear weights
   std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
@@ -548,13 +549,17 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
 
 extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
+  if (variant >= 110 && variant <= 112) {  // small-batch one-launch form (entry + first contraction): off / auto / forced
+    m->fuse_entry = variant - 110;
+    return IKF_OK;
+  }
   if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
     m->gemm_variant = 100;
     m->tile_cfg = variant - 101;
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -624,7 +629,14 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
     const int n_mid = d.n_hidden - 1;
-    IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
+    // small batches: the entry kernel and the first hidden contraction run as one launch (k_entry_gemm_skinny).  In the
+    // chain it pays with the 32x32 tiles (<= 256 rows: 0.56 -> 0.53 ms per call); with the 32x64 tiles (257..512 rows) the
+    // one launch takes as long as the two it replaces (18.4 us against 5.5 + 13.0), so those keep the two-launch form
+    // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
+    const bool one_launch = !split && (m->fuse_entry == 2 || (m->fuse_entry == 1 && cfg == fused_skinny32_cfg())) &&
+                            entry_gemm_ok(cfg, nr, d.width, d.D, pend.P ? pend.n_out : 0) &&
+                            m->w_mid_frag[(size_t)(2 * b + which - 1) * 3] != nullptr;
+    if (!one_launch) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     float* cur = m->hA;
     float* nxt = m->hB;
     for (int l = 0; l < n_mid; ++l) {
@@ -641,7 +653,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
       } else {
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
         g.Wf = m->w_mid_frag[(size_t)(2 * b + which - 1) * 3 + l];
-        IKF_HIP(launch_flow_gemm(last, cfg, g, s));
+        if (l == 0 && one_launch) IKF_HIP(launch_entry_gemm(w.n_x + d.n_pose, last, cfg, e, g, s));
+        else IKF_HIP(launch_flow_gemm(last, cfg, g, s));
       }
       IKF_HIP(prof_mark(m, s));
       float* tmp = cur; cur = nxt; nxt = tmp;

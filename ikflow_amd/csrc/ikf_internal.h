@@ -136,6 +136,9 @@ int fused_slots(int cfg, int width);            // partial-sum slots that config
 int fused_max_slots(int width);
 hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s);
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s);
+// small batches: k_subnet_entry + the first hidden contraction in one launch (k_entry_gemm_skinny)
+bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out);
+hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e, const FusedGemmArgs& a, hipStream_t s);
 extern int g_entry_geom_override;  // probes: force an entry-kernel geometry
 hipError_t launch_flow_finalize(const FinalizeArgs& a, hipStream_t s);
 const char* fused_kernel_name();

@@ -237,7 +237,9 @@ const char* ikf_split_kernel_name(void);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
 const char* ikf_dominant_kernel_name(void);
 /* Select the flow pipeline: -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly,
- * 0..8 the unfused 4-kernel form with that contraction tile variant. Returns IKF_ERR_BAD_ARGUMENT if unknown. */
+ * 0..8 the unfused 4-kernel form with that contraction tile variant; 110 / 111 / 112: the small-batch one-launch form
+ * (entry kernel + first hidden contraction) off / automatic (default) / forced wherever it is supported.
+ * Returns IKF_ERR_BAD_ARGUMENT if unknown. */
 ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 
 #ifdef __cplusplus

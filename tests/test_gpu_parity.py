@@ -1021,3 +1021,44 @@ def test_softflow_scale_and_zero_row_calls():
     assert sol.shape == (0, 7) and valid.shape == (0,)
     sol, valid = eng.generate_exact(empty_p, (1, 3), 1e-3, 0.1, seed_fn=lambda r, idx, rep: empty_q)
     assert sol.shape == (0, 7) and valid.shape == (0,)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(nb_nodes=3, dim=7, n_hidden=3, width=1024),                       # the released shape
+    dict(nb_nodes=2, dim=9, n_hidden=2, width=256),                        # TINY's: the one-launch form is also the LAST contraction
+    dict(nb_nodes=2, dim=10, n_hidden=4, width=512, robot_name="fetch_arm"),
+    dict(nb_nodes=2, dim=8, n_hidden=2, width=1024, robot_name="fetch"),
+])
+def test_small_batch_one_launch_form_equals_two_launches(kw):
+    """k_entry_gemm_skinny (entry kernel + first hidden contraction in one launch, <= 256 tiles; the first Linear on the matrix
+    pipe, accumulating from the bias with k ascending) against the two-launch form it replaces (ikf_set_gemm_variant 110 =
+    off, 112 = forced for every batch it supports; 111 = the default: taken with the 32x32 tiles only): the f32 MFMA is an fmaf chain, so the two forms must give identical bits; and both match the oracle."""
+    robot, hp, lay, sd = custom_model(seed=12, gain=1.5, **kw)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n_max = 512
+    _, poses = reachable_poses(robot, n_max, 95)
+    lat = latents(n_max, lay.dim, 96)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
+    for n in (1, 31, 32, 33, 200, 256, 257, 400, 512):
+        P, L = poses[:n].to(DEV), lat[:n].to(DEV)
+        kw_n = dict(n=(1 if n == 1 else None), latent=L, clamp_to_joint_limits=False)
+        eng.set_gemm_variant(110)
+        two = s.generate_ik_solutions(P, **kw_n)
+        eng.set_gemm_variant(112)
+        one = s.generate_ik_solutions(P, **kw_n)
+        assert torch.equal(one, two), f"{kw} n={n}: max diff {(one - two).abs().max().item():.3e}"
+        err = ((one.cpu() - ref[:n]).abs() / torch.clamp(ref[:n].abs(), min=1.0)).max().item()
+        assert err <= FLOW_TOL, f"{kw} n={n}: {err:.2e}"
+    # softflow column and the exact path (tile-major pose gather through pose_idx) go through it too
+    cond = torch.cat([poses[:100], torch.full((100, 1), 0.4)], dim=1)
+    if lay.dim_cond == 8:
+        got = eng.generate_approx(poses[:100].to(DEV), lat[:100].to(DEV), False, softflow_scale=0.4).cpu()
+        assert (got - fo.run_inference_torch(sd, lay, robot, lat[:100], cond, False)).abs().max().item() <= 10 * FLOW_TOL
+    res = []
+    for variant in (110, 112):
+        eng.set_gemm_variant(variant)
+        torch.manual_seed(5)
+        res.append(s.generate_exact_ik_solutions(poses[:100].to(DEV), pos_error_threshold=0.05, rot_error_threshold=0.5))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    eng.set_gemm_variant(111)

@@ -99,6 +99,34 @@ int main(int argc, char** argv) {
       printf("k_subnet_entry<11> M=%d geometry %d: %.2f us/launch\n", M, geom, best);
     }
     ikf::g_entry_geom_override = argc > 4 ? atoi(argv[4]) : 0;
+    if (M <= 512) {  // the one-launch small-batch form (entry + first hidden contraction) against the two launches it replaces
+      float *Wf, *Cq; CK(hipMalloc(&Wf, (size_t)N * K * 4)); CK(ikf::launch_wfrag_pack(W, N, K, Wf, 0)); CK(hipMalloc(&Cq, (size_t)Mp * N * 4));
+      ikf::FusedGemmArgs g{}; g.A = h; g.W = W; g.Wf = Wf; g.bias = b; g.C = Cq; g.M = M; g.N = N; g.K = K; g.slope = 0.01f;
+      const int cfg = M <= 256 ? 6 : 4;
+      ikf::g_entry_geom_override = -1;
+      for (int form = 0; form < 2; ++form) {
+        float best = 1e9f;
+        for (int rep = 0; rep < 3; ++rep) {
+          for (int i = 0; i < iters + 10; ++i) {
+            if (i == 10) CK(hipEventRecord(e0, 0));
+            if (form == 0) { CK(ikf::launch_subnet_entry(IN, e, 0)); CK(ikf::launch_flow_gemm(false, cfg, g, 0)); }
+            else CK(ikf::launch_entry_gemm(IN, false, cfg, e, g, 0));
+          }
+          CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          best = fminf(best, 1000.0f * ms / iters);
+        }
+        printf("%s M=%d cfg %d: %.2f us\n", form == 0 ? "k_subnet_entry + k_flow_gemm_skinny" : "k_entry_gemm_skinny", M, cfg, best);
+      }
+      unsigned long long* tb; const int nb = 4096;
+      CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
+      ikf::launch_entry_gemm(IN, false, cfg, e, g, 0); ikf::launch_entry_gemm(IN, false, cfg, e, g, 0); CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> ht((size_t)nb * 64); CK(hipMemcpy(ht.data(), tb, ht.size() * 8, hipMemcpyDeviceToHost));
+      for (int bI : {0, 100}) { const unsigned long long* r = &ht[(size_t)bI * 64];
+        printf("one-launch block %3d: pending %llu  publish+first-Linear %llu  K loop %llu  tail %llu  total %llu cycles\n", bI, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[41] - r[3], r[41] - r[0]); }
+      return 0;
+    }
     unsigned long long* tb; const int nb = 4096;
     CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
