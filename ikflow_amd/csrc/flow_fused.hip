@@ -63,36 +63,60 @@ __device__ __forceinline__ int state_src(const PendingCoupling& pc, int d) {
   return (pc.P != nullptr && pc.which == 2) ? pc.perm_inv[d] : d;  // PermuteRandom rev: out[:, d] = cat[:, perm_inv[d]]
 }
 
+// The loads of a pending coupling (state element, bias and the first 32 partial-sum slots of each of this thread's items),
+// split from their use so that a kernel can issue them BEFORE its other prefetches: VMEM returns in order, and a wait in
+// front of the slot sums would otherwise also wait for whatever was queued ahead of them.
+template <int ITEMS>
+struct PendingLoads {
+  float xv[ITEMS], bias[ITEMS], a[ITEMS][32];
+};
+
 template <int NT, int R>
-__device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const float* __restrict__ x_src,
-                                                    int D, int L1, float clamp, int m0, int M, float* cat, float* sums,
-                                                    int t) {
+__device__ __forceinline__ void pending_issue_loads(const PendingCoupling& pc, const float* __restrict__ x_src, int D, int L1,
+                                                    int m0, int M, int t, PendingLoads<(R * ROWBUF + NT - 1) / NT>& pl) {
+  constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
+  const int nl = (pc.which == 1) ? D - L1 : L1;
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = t + it * NT, r = idx / ROWBUF, d = idx % ROWBUF;
+    int gr = m0 + r;
+    gr = gr < M ? gr : M - 1;
+    pl.xv[it] = (idx < R * ROWBUF && d < D) ? x_src[(size_t)gr * D + d] : 0.f;
+    const bool has_sum = pc.P != nullptr && idx < R * ROWBUF && d < 2 * nl;
+    const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + d;  // P rows are padded to the tile: no clamp needed
+    pl.bias[it] = has_sum ? pc.b_last[d] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) pl.a[it][q] = (has_sum && q < pc.slots) ? p[(size_t)q * pc.slot_stride] : 0.f;
+  }
+}
+
+// Phase A: one thread per (row, subnet output o) sums that output's slots in fixed order (bias, slot 0, slot 1, ..) and parks
+// the sum in LDS.  Phase B: one thread per (row, state element) applies the coupling (see above).  Ends with a barrier.
+template <int NT, int R>
+__device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const PendingLoads<(R * ROWBUF + NT - 1) / NT>& pl,
+                                                    int D, int L1, float clamp, int m0, float* cat, float* sums, int t) {
   constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
   const int L2 = D - L1;
   // which == 1: y2 = (x2 - t1) * exp(-s1), x1 untouched.   which == 2: y1 = (x1 - t2) * exp(-s2), x2 (= y2) untouched
   const int nl = (pc.which == 1) ? L2 : L1;
   const int off = (pc.which == 1) ? L1 : 0;
-  float xv[ITEMS];
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {  // the state element of phase B is requested before the slot loads
-    const int idx = t + it * NT, r = idx / ROWBUF, d = idx % ROWBUF;
-    int gr = m0 + r;
-    gr = gr < M ? gr : M - 1;
-    xv[it] = (idx < R * ROWBUF && d < D) ? x_src[(size_t)gr * D + d] : 0.f;
-  }
   if (pc.P != nullptr) {
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = t + it * NT, r = idx / ROWBUF, o = idx % ROWBUF;
       if (idx >= R * ROWBUF || o >= 2 * nl) continue;
-      const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + o;  // P rows are padded to the tile: no clamp needed
-      float sv = pc.b_last[o];
-      for (int s0 = 0; s0 < pc.slots; s0 += 32) {
-        float a[32];
+      float sv = pl.bias[it];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) a[q] = (s0 + q < pc.slots) ? p[(size_t)(s0 + q) * pc.slot_stride] : 0.f;
+      for (int q = 0; q < 32; ++q) sv += pl.a[it][q];
+      if (pc.slots > 32) {  // wider than any released model's tiles: the remaining slots in chunks of 32
+        const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + o;
+        for (int s0 = 32; s0 < pc.slots; s0 += 32) {
+          float a[32];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) sv += a[q];
+          for (int q = 0; q < 32; ++q) a[q] = (s0 + q < pc.slots) ? p[(size_t)(s0 + q) * pc.slot_stride] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) sv += a[q];
+        }
       }
       sums[r * ROWBUF + o] = sv;
     }
@@ -102,7 +126,7 @@ __device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, c
   for (int it = 0; it < ITEMS; ++it) {
     const int idx = t + it * NT, r = idx / ROWBUF, d = idx % ROWBUF;
     if (idx >= R * ROWBUF || d >= D) continue;
-    float v = xv[it];
+    float v = pl.xv[it];
     if (pc.P != nullptr && d >= off && d < off + nl) {
       const int j = d - off;
       const float s_cl = clamp * (0.636f * atanf(sums[r * ROWBUF + j]));
@@ -126,6 +150,8 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * ER;
   const int M = e.M, D = e.D;
+  PendingLoads<(ER * ROWBUF + NT - 1) / NT> pl;
+  pending_issue_loads<NT, ER>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);  // the critical path's loads go first
   // this thread's slice of the first Linear (first column group) is fetched up front: its L2 latency hides behind the
   // pending-coupling phase below
   // Column split for small batches (gridDim.y workgroups share a row group, each redoing the cheap pending phase): the
@@ -164,7 +190,7 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
     }
   }
   IKF_TSTAMP(0)
-  finish_pending_rows<NT, ER>(e.pend, e.x_src, D, e.L1, e.clamp, m0, M, cat, U, t);
+  finish_pending_rows<NT, ER>(e.pend, pl, D, e.L1, e.clamp, m0, cat, U, t);
   IKF_TSTAMP(1)
   // publish the new state and assemble u = [x_part, pose, 0-pad]
 #pragma unroll
@@ -528,7 +554,9 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
   __shared__ float cat[R * ROWBUF], sums[R * ROWBUF];
   const int t = threadIdx.x;
   const int m0 = blockIdx.x * R;
-  finish_pending_rows<NT, R>(f.pend, f.x_src, f.D, f.L1, f.clamp, m0, f.M, cat, sums, t);
+  PendingLoads<(R * ROWBUF + NT - 1) / NT> pl;
+  pending_issue_loads<NT, R>(f.pend, f.x_src, f.D, f.L1, m0, f.M, t, pl);
+  finish_pending_rows<NT, R>(f.pend, pl, f.D, f.L1, f.clamp, m0, cat, sums, t);
   // FixedLinearTransform rev: (x - b).mm(M_inv); [:, :ndof]; clamp_to_joint_limits
   const int D = f.D;
   for (int idx = t; idx < R * ROWBUF; idx += NT) {
@@ -826,24 +854,10 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e
   const int nh = wave % NH, kq = wave / NH;
   const int M = e.M, D = e.D;
 
-  // ---- pending coupling, load half: this thread's state element and the partial-sum slots of its (row, output) - issued
-  // FIRST so that the wait in front of their use does not also wait for the operand prefetches queued behind them (VMEM
-  // returns in order).  One item per thread (R * ROWBUF = 512 <= NT); <= 32 slots for every small-batch tile at K <= 1024.
-  const PendingCoupling& pc = e.pend;
-  const int p_nl = (pc.which == 1) ? D - e.L1 : e.L1;
-  const int p_off = (pc.which == 1) ? e.L1 : 0;
-  const int pr = t / ROWBUF, pd = t % ROWBUF;  // (row, state element / subnet output) of this thread
-  float p_xv = 0.f, p_a[32], p_b = 0.f;
-  {
-    int gr = m0 + pr;
-    gr = gr < M ? gr : M - 1;
-    if (t < R * ROWBUF && pd < D) p_xv = e.x_src[(size_t)gr * D + pd];
-    const bool has_sum = pc.P != nullptr && t < R * ROWBUF && pd < 2 * p_nl;
-    const float* p = pc.P ? pc.P + (size_t)(m0 + pr) * IKF_PSTRIDE + pd : nullptr;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) p_a[q] = (has_sum && q < pc.slots) ? p[(size_t)q * pc.slot_stride] : 0.f;
-    if (has_sum) p_b = pc.b_last[pd];
-  }
+  // ---- pending coupling, load half - issued FIRST so that the wait in front of the slot sums does not also wait for the
+  // operand prefetches queued behind them (VMEM returns in order)
+  PendingLoads<(R * ROWBUF + NT - 1) / NT> pl;
+  pending_issue_loads<NT, R>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);
 
   // ---- W fragments of k tiles 0 and 1 of the contraction (independent of everything below)
   constexpr int WTILE = KKS * KKG * 256;
@@ -897,26 +911,7 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e
     pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
   }
   IKF_TSTAMP(0)
-  // ---- pending coupling, compute half (same order of operations as finish_pending_rows: bias, slot 0, slot 1, ...)
-  if (pc.P != nullptr) {
-    if (t < R * ROWBUF && pd < 2 * p_nl) {
-      float sv = p_b;
-#pragma unroll
-      for (int q = 0; q < 32; ++q) sv += p_a[q];
-      sums[pr * ROWBUF + pd] = sv;
-    }
-    __syncthreads();
-  }
-  if (t < R * ROWBUF && pd < D) {
-    float v = p_xv;
-    if (pc.P != nullptr && pd >= p_off && pd < p_off + p_nl) {
-      const int j = pd - p_off;
-      const float s_cl = e.clamp * (0.636f * atanf(sums[pr * ROWBUF + j]));
-      v = (v - sums[pr * ROWBUF + p_nl + j]) * expf(-s_cl);
-    }
-    cat[pr * ROWBUF + pd] = v;
-  }
-  __syncthreads();
+  finish_pending_rows<NT, R>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
   IKF_TSTAMP(1)
   if (t < R * ROWBUF) {
     if (tn == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];

@@ -118,6 +118,52 @@ int main(int argc, char** argv) {
         }
         printf("%s M=%d cfg %d: %.2f us\n", form == 0 ? "k_subnet_entry + k_flow_gemm_skinny" : "k_entry_gemm_skinny", M, cfg, best);
       }
+      // chain-like rotation: 24 subnets, each with its own two weight images (2 x 24 x 4 MB stream through the caches as in a real
+      // call) and partial sums rewritten by the preceding launch: [entry (+) contraction<false>] -> contraction<true> -> ...
+      {
+        const int NSUB = 24;
+        std::vector<float*> Wr(2 * NSUB);
+        for (auto& pw : Wr) { CK(hipMalloc(&pw, (size_t)N * K * 4)); CK(hipMemcpy(pw, Wf, (size_t)N * K * 4, hipMemcpyDeviceToDevice)); }
+        float* wl; CK(hipMalloc(&wl, (size_t)16 * N * 4)); CK(hipMemset(wl, 0, (size_t)16 * N * 4));
+        ikf::FusedGemmArgs g2 = g; g2.A = Cq; g2.C = nullptr; g2.w_last = wl; g2.n_out = 6; g2.P_out = P; g2.p_slot_stride = (long long)Mp * 16;
+        ikf::EntryArgs e2 = e; e2.pend.slots = cfg == 6 ? 32 : 16;
+        for (int form = 0; form < 2; ++form) {
+          float best = 1e9f;
+          for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0, 0));
+            for (int it = 0; it < 10; ++it)
+              for (int sI = 0; sI < NSUB; ++sI) {
+                g.Wf = Wr[2 * sI]; g2.Wf = Wr[2 * sI + 1];
+                if (form == 0) { CK(ikf::launch_subnet_entry(IN, e2, 0)); CK(ikf::launch_flow_gemm(false, cfg, g, 0)); }
+                else CK(ikf::launch_entry_gemm(IN, false, cfg, e2, g, 0));
+                CK(ikf::launch_flow_gemm(true, cfg, g2, 0));
+              }
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best = fminf(best, 1000.0f * ms / (10 * NSUB));
+          }
+          printf("chain rotation, %s: %.2f us per subnet\n", form == 0 ? "three launches" : "two launches (one-launch form)", best);
+        }
+        {  // in-rotation timeline of the one-launch kernel (stamps of the last launch survive)
+          unsigned long long* tb2; const int nb2 = 4096;
+          CK(hipMalloc(&tb2, (size_t)nb2 * 64 * 8)); CK(hipMemset(tb2, 0, (size_t)nb2 * 64 * 8));
+          CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb2, sizeof(tb2)));
+          for (int sI = 0; sI < NSUB; ++sI) {
+            g.Wf = Wr[2 * sI]; g2.Wf = Wr[2 * sI + 1];
+            CK(ikf::launch_entry_gemm(IN, false, cfg, e2, g, 0));
+            if (sI + 1 < NSUB) CK(ikf::launch_flow_gemm(true, cfg, g2, 0));
+          }
+          CK(hipDeviceSynchronize());
+          std::vector<unsigned long long> ht2((size_t)nb2 * 64); CK(hipMemcpy(ht2.data(), tb2, ht2.size() * 8, hipMemcpyDeviceToHost));
+          unsigned long long t0min = ~0ull, tend = 0;
+          for (int bI = 0; bI < 256; ++bI) { if (ht2[bI * 64] && ht2[bI * 64] < t0min) t0min = ht2[bI * 64]; if (ht2[bI * 64 + 41] > tend) tend = ht2[bI * 64 + 41]; }
+          printf("in rotation: kernel span first-start..last-end %llu cycles\n", tend - t0min);
+          for (int bI : {0, 100, 255}) { const unsigned long long* r = &ht2[(size_t)bI * 64];
+            printf("in rotation block %3d: start+%llu pending %llu  publish+first-Linear %llu  K loop %llu  tail %llu  total %llu cycles\n", bI, r[0] - t0min, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[41] - r[3], r[41] - r[0]); }
+          unsigned long long z = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &z, sizeof(z)));
+        }
+        g.Wf = Wf;
+      }
       unsigned long long* tb; const int nb = 4096;
       CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
       CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
