@@ -655,14 +655,19 @@ __device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx
       *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
     }
     __syncthreads();
-    if (wave == 0) {  // one slot per tile (64 columns: same MFMA order as the large tiles; 32 columns: half slots)
-      floatx16 pacc;
+    // one slot per tile.  Four waves (one per SIMD) contract a quarter of the tile's columns each - 8 (4) MFMAs instead of
+    // one wave's 32 (16) - and wave 0 adds the quarters in fixed order 0, 1, 2, 3 through LDS (red[] is dead by now)
+    constexpr int NQW = 4, CPQ = BN / NQW;
+    static_assert(CPQ % 8 == 0, "a wave's column quarter is a whole number of 8-column MFMA groups");
+    float* part = smem;  // [NQW][8][64]
+    floatx16 pacc;
+    if (wave < NQW) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-      const float* pa = Wl + (lane & 31) * LDT + (lane >> 5) * 4;
-      const float* pb = T + (lane & 31) * LDT + (lane >> 5) * 4;
+      const float* pa = Wl + (lane & 31) * LDT + wave * CPQ + (lane >> 5) * 4;
+      const float* pb = T + (lane & 31) * LDT + wave * CPQ + (lane >> 5) * 4;
 #pragma unroll
-      for (int ks = 0; ks < BN / 8; ++ks) {
+      for (int ks = 0; ks < CPQ / 8; ++ks) {
         const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
         const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
@@ -670,11 +675,22 @@ __device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
       }
+      // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7
+      if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) part[(wave * 8 + r) * 64 + lane] = pacc[r];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
       float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
+        float v = pacc[r];
+#pragma unroll
+        for (int w = 1; w < NQW; ++w) v += part[(w * 8 + r) * 64 + lane];
         const int o = (r & 3) + 8 * (r >> 2) + row_h;
-        pout[o] = pacc[r];
+        pout[o] = v;
       }
     }
   }
