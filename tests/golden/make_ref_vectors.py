@@ -8,6 +8,10 @@ but four pieces of /root/reference/ikflow/model.py on the hot path depend on not
   * ``IkFlowFixedLinearTransform.forward``    ikflow/model.py:191-233  y = x.mm(M) + b ;  rev: (x - b).mm(M_inv)   (the in-tree
                                                                        twin of FrEIA's FixedLinearTransform, graph node 0)
   * ``InvertibleSigmoidFlipped.forward``      ikflow/model.py:120-146  rev: 1 / (1 + exp(-x))  (sigmoid_on_output graph)
+and three more of the path's helpers that are pure torch / numpy:
+  * ``draw_latent``                           ikflow/ikflow_solver.py:16-29        the latent sampler (row A0)
+  * ``calculate_joint_limits_exceeded``       ikflow/evaluation_utils.py:100-112   strict-inequality limit flags (f-2)
+  * ``_get_target_pose_batch``                ikflow/evaluation_utils.py:22-34     single-pose tiling rule
 
 They are taken out of the reference file with ``ast`` at generation time and executed - functions as they are, the two
 ``forward`` methods as plain functions called with a namespace object in place of ``self`` that carries the tensors
@@ -107,6 +111,38 @@ def main():
     (logit,), lj = ns["InvertibleSigmoidFlipped_forward"](None, (x01,), rev=False)
     out.update(sig_rev_in=z.numpy().copy(), sig_rev_out=sig.numpy().copy(), sig_rev_logdet=sj.numpy().copy(),
                sig_fwd_out=logit.numpy().copy(), sig_fwd_logdet=lj.numpy().copy())
+    # --- draw_latent (ikflow_solver.py:16-29), calculate_joint_limits_exceeded / _get_target_pose_batch (evaluation_utils.py)
+    import typing
+
+    def load_fns(path, names, extra):
+        tree = ast.parse(open(path).read())
+        keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+        env = {"torch": torch, "np": np, "Tuple": typing.Tuple, "List": typing.List, "Optional": typing.Optional}
+        env.update(extra)
+        exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), env)
+        return env
+
+    sol = load_fns("/root/reference/ikflow/ikflow_solver.py", {"draw_latent"}, {})
+    torch.manual_seed(1234)
+    out["latent_gaussian"] = sol["draw_latent"]("gaussian", 0.75, (5, 7), "cpu").numpy().copy()
+    out["latent_uniform"] = sol["draw_latent"]("uniform", 2.0, (5, 7), "cpu").numpy().copy()
+    # PT_NP_TYPE is jrl.config's annotation alias for "numpy array or torch tensor"; only the annotation needs the name
+    ev = load_fns("/root/reference/ikflow/evaluation_utils.py", {"calculate_joint_limits_exceeded", "_get_target_pose_batch"},
+                  {"PT_NP_TYPE": typing.Union[np.ndarray, torch.Tensor]})
+    qg = torch.Generator().manual_seed(11)
+    lo7 = torch.tensor([l[0] for l in limits])
+    hi7 = torch.tensor([l[1] for l in limits])
+    cfg = lo7 + (hi7 - lo7) * (1.2 * torch.rand(400, 7, generator=qg) - 0.1)  # ~1/3 of the rows leave the limits
+    cfg[:7] = lo7.repeat(7, 1)                                                   # exactly on a limit: not exceeded (strict)
+    cfg[7:14] = hi7.repeat(7, 1)
+    cfg[14, 3] = float(np.nextafter(np.float32(hi7[3]), np.float32(1e9)))        # one float32 ulp beyond: exceeded
+    cfg[15, 5] = float(np.nextafter(np.float32(lo7[5]), np.float32(-1e9)))
+    out["limits_cfg"] = cfg.numpy().copy()
+    out["limits_exceeded"] = ev["calculate_joint_limits_exceeded"](cfg, limits).numpy().copy()
+    one = torch.arange(7, dtype=torch.float32)
+    out["tpb_single"] = ev["_get_target_pose_batch"](one, 4).numpy().copy()
+    batch = cfg[:5].clone()
+    out["tpb_batch_is_identity"] = np.array(ev["_get_target_pose_batch"](batch, 5) is batch)
     path = os.path.join(HERE, "ref_vectors.npz")
     np.savez(path, **out)
     print(path, os.path.getsize(path), "bytes")

@@ -225,3 +225,24 @@ def test_reference_fixed_linear_transform_and_flipped_sigmoid_vectors():
     Mp, Mp_inv, bp = pm.fixed_linear_transform(pm.layout_from(hp, robot), robot)
     np.testing.assert_array_equal(Mp_inv, M_inv)
     np.testing.assert_array_equal(bp, b)
+
+
+def test_reference_helper_vectors_latent_limits_tiling():
+    """ikflow_solver.draw_latent (:16-29), evaluation_utils.calculate_joint_limits_exceeded (:100-112) and
+    _get_target_pose_batch (:22-34) executed from the reference files: the product's host-side mirrors and the oracle
+    reproduce them (the HIP limit kernels are checked against the same vectors in tests/test_gpu_parity.py)."""
+    from ikflow_amd import evaluation_utils as eu
+    from ikflow_amd.ikflow_solver import draw_latent
+
+    z = np.load(os.path.join(GOLD, "ref_vectors.npz"))
+    torch.manual_seed(1234)
+    np.testing.assert_array_equal(draw_latent("gaussian", 0.75, (5, 7), "cpu").numpy(), z["latent_gaussian"])
+    np.testing.assert_array_equal(draw_latent("uniform", 2.0, (5, 7), "cpu").numpy(), z["latent_uniform"])
+    cfg = torch.from_numpy(z["limits_cfg"])
+    got = ko.calculate_joint_limits_exceeded(cfg, O("panda").actuated_joints_limits)
+    np.testing.assert_array_equal(got.numpy(), z["limits_exceeded"])
+    assert not z["limits_exceeded"][:14].any() and z["limits_exceeded"][14] and z["limits_exceeded"][15]  # strict, float32
+    one = torch.arange(7, dtype=torch.float32)
+    np.testing.assert_array_equal(eu._get_target_pose_batch(one, 4).numpy(), z["tpb_single"])
+    batch = cfg[:5].clone()
+    assert bool(z["tpb_batch_is_identity"]) and eu._get_target_pose_batch(batch, 5) is batch
