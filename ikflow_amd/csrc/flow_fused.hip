@@ -202,6 +202,7 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
   }
   __syncthreads();
   IKF_TSTAMP(2)
+  unsigned range_max = 0;  // split_out: running maximum of the |hi| halves written (f16x3 range guard)
   for (int cc = tc; cc < n4_per; cc += CPW) {
     const int c4 = c4_base + cc;
     floatx4 w[IN];
@@ -243,7 +244,11 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
         for (int q = 0; q < 4; ++q) {
           hi[q] = (_Float16)acc[q];
           lo[q] = (_Float16)((acc[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
-          if (split_out_of_range(acc[q]) && e.split_flag) atomicOr(e.split_flag, 1);
+        }
+        {
+          typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+          const uint2_t hb = __builtin_bit_cast(uint2_t, hi);
+          range_max = range_track(range_track(range_max, hb.x), hb.y);
         }
         char* rowp = reinterpret_cast<char*>(e.h_out) + (size_t)(m0 + r) * e.width * 4 + (size_t)(c4 >> 3) * 128 + (c4 & 7) * 8;
         *reinterpret_cast<half4*>(rowp) = hi;
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
       }
     }
   }
+  if (e.split_out && e.split_flag && range_hit(range_max)) atomicOr(e.split_flag, 1);
   IKF_TSTAMP(3)
 }
 

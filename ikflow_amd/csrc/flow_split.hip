@@ -252,7 +252,7 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
     __syncthreads();
     char* Cb = reinterpret_cast<char*>(g.C);
     constexpr int CH = BN / 8;  // 8-column chunks per row
-    bool range_bad = false;
+    unsigned range_max = 0;
     for (int idx = t; idx < BM * CH; idx += NT) {
       const int rl = idx / CH, ch = idx - rl * CH;
       const floatx4 v0 = *reinterpret_cast<const floatx4*>(T + rl * LDT + ch * 8);
@@ -264,14 +264,18 @@ __global__ __launch_bounds__(SplitCfg<CFG>::WAVES_M* SplitCfg<CFG>::WAVES_N * 64
         lo[q] = (_Float16)((v0[q] - (float)hi[q]) * IKF_SPLIT_SCALE);
         hi[4 + q] = (_Float16)v1[q];
         lo[4 + q] = (_Float16)((v1[q] - (float)hi[4 + q]) * IKF_SPLIT_SCALE);
-        range_bad = range_bad || split_out_of_range(v0[q]) || split_out_of_range(v1[q]);
+      }
+      {
+        typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+        const uint4_t hb = __builtin_bit_cast(uint4_t, hi);
+        range_max = range_track(range_track(range_track(range_track(range_max, hb.x), hb.y), hb.z), hb.w);
       }
       const int col = n0 + ch * 8;  // global column of the chunk; block of 32 columns = one 128-B line
       char* p = Cb + (size_t)(m0 + rl) * N * 4 + (size_t)(col >> 5) * 128 + (col & 31) * 2;
       *reinterpret_cast<half8*>(p) = hi;
       *reinterpret_cast<half8*>(p + 64) = lo;
     }
-    if (range_bad && g.flag) atomicOr(g.flag, 1);
+    if (range_hit(range_max) && g.flag) atomicOr(g.flag, 1);
   } else {
     // last Linear restricted to this tile's columns, in exact f32 MFMA (identical to k_flow_gemm<true>): one slot per 64 columns
     float* Wl = smem + BM * LDT;

@@ -166,6 +166,20 @@ struct SplitGemmArgs {
 };
 // true when a does not fit the f16 hi part of the split (|a| > 65504, inf, NaN)
 __device__ __forceinline__ bool split_out_of_range(float a) { return !(__builtin_fabsf(a) <= 65504.0f); }
+// The same test on converted operands, two at a time: a value beyond the f16 range (or non-finite) converts to an f16 with all
+// exponent bits set, i.e. |half| >= 0x7C00.  range_track() keeps the running maximum of the packed |hi| halves (one v_and and
+// one v_pk_max_u16 per two elements - the float test costs a compare and a scalar OR per element); range_hit() reads it once.
+typedef unsigned short ikf_ushort2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned range_track(unsigned running, unsigned packed_hi_halves) {
+#ifdef IKF_NO_RANGE_FLAG  // probes only: A/B of what the detection costs
+  return running;
+#else
+  const ikf_ushort2 a = __builtin_bit_cast(ikf_ushort2, running);
+  const ikf_ushort2 b = __builtin_bit_cast(ikf_ushort2, packed_hi_halves & 0x7FFF7FFFu);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, b));
+#endif
+}
+__device__ __forceinline__ bool range_hit(unsigned running) { return (running & 0xFFFFu) >= 0x7C00u || (running >> 16) >= 0x7C00u; }
 hipError_t launch_split_gemm(bool epi_red, int cfg, const SplitGemmArgs& a, hipStream_t s);
 int split_pick_cfg(long long rows, int width);
 int split_slots(int cfg, int width);
