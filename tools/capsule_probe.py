@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0,'/root/repo')
+"""Clearance of the approximate Panda capsule model (ikflow_amd.robots.PANDA_APPROX_CAPSULES) at named postures, colliding
+fraction of uniformly random configurations, and the capsule pairs that contribute.  GPU box only."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ikflow_amd.robots import Panda
 r = Panda().use_approximate_collision_model()
