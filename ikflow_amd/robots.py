@@ -119,6 +119,33 @@ class Robot:
         hi = np.array([l[1] for l in self._limits]) - joint_limit_eps
         return (lo + (hi - lo) * rng.random((n, self.ndof))).astype(np.float32)
 
+    def sample_joint_angles_and_poses(self, n: int, joint_limit_eps: float = 0.0, only_non_self_colliding: bool = False,
+                                      tqdm_enabled: bool = False, return_torch: bool = False, device=None,
+                                      rng: Optional[np.random.Generator] = None):
+        """(q [n x ndof], poses [n x 7]) like jrl.Robot.sample_joint_angles_and_poses, which the reference's tests and
+        harnesses draw their target poses from (tests/ikflow_solver_test.py:73-75, scripts/benchmark_runtime.py).  FK runs
+        on the GPU engine; numpy arrays come back unless return_torch.  only_non_self_colliding needs a collision model
+        (Robot.set_collision_capsules / use_approximate_collision_model): colliding samples are redrawn."""
+        import torch
+
+        from ikflow_amd.engine import kinematics_engine_for
+
+        eng = kinematics_engine_for(self, device)
+        rng = np.random.default_rng() if rng is None else rng
+        q = torch.tensor(self.sample_joint_angles(n, joint_limit_eps, rng), device=eng.device)
+        if only_non_self_colliding:
+            assert self.has_collision_model, "only_non_self_colliding needs a collision model (Robot.set_collision_capsules)"
+            for _ in range(64):
+                bad = self.config_self_collides(q)
+                k = int(bad.sum().item())
+                if k == 0:
+                    break
+                q[bad] = torch.tensor(self.sample_joint_angles(k, joint_limit_eps, rng), device=eng.device)
+        poses = eng.forward_kinematics(q)
+        if return_torch:
+            return q, poses
+        return q.cpu().numpy(), poses.cpu().numpy()
+
     # -- engine-backed tensor methods (jrl.Robot API surface used by ikflow) --------------------------
     def _engine(self, like):
         from ikflow_amd.engine import kinematics_engine_for

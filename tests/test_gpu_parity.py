@@ -1111,3 +1111,21 @@ def test_hip_path_against_the_reference_statement_fixtures():
         total += ref_valid.numel()
         assert torch.equal(sol.cpu()[~valid.cpu()], torch.zeros_like(sol.cpu()[~valid.cpu()]))
     assert agree >= 0.93 * total, (agree, total)
+
+
+def test_sample_joint_angles_and_poses_like_the_reference_tests_use_it():
+    """jrl.Robot.sample_joint_angles_and_poses as the reference's tests call it (tests/ikflow_solver_test.py:73-75): numpy in
+    the limits, poses = FK(q) (checked with the oracle), colliding samples redrawn when asked."""
+    from ikflow_amd.robots import Panda
+
+    robot = Panda()
+    q, poses = robot.sample_joint_angles_and_poses(500, rng=np.random.default_rng(0))
+    assert isinstance(q, np.ndarray) and q.shape == (500, 7) and poses.shape == (500, 7)
+    lim = np.array(O(robot).actuated_joints_limits)
+    assert (q >= lim[:, 0]).all() and (q <= lim[:, 1]).all()
+    ref = ko.forward_kinematics(robot, torch.from_numpy(q)).numpy()
+    assert np.abs(poses[:, :3] - ref[:, :3]).max() <= 2e-6
+    robot.use_approximate_collision_model()
+    q2, _ = robot.sample_joint_angles_and_poses(2000, only_non_self_colliding=True, tqdm_enabled=False, return_torch=True,
+                                                rng=np.random.default_rng(1))
+    assert q2.is_cuda and not bool(robot.config_self_collides(q2).any())
