@@ -1129,3 +1129,32 @@ def test_sample_joint_angles_and_poses_like_the_reference_tests_use_it():
     q2, _ = robot.sample_joint_angles_and_poses(2000, only_non_self_colliding=True, tqdm_enabled=False, return_torch=True,
                                                 rng=np.random.default_rng(1))
     assert q2.is_cuda and not bool(robot.config_self_collides(q2).any())
+
+
+def test_exact_ik_one_million_poses():
+    """BASELINE config 5's size through the exact path on one GPU: 1,000,000 target poses, repeat_counts (1, 3, 10) with
+    seeded random weights = the schedule's worst case (~14 M flow rows in 16384-row chunks, 42 M LM row-iterations, the
+    multi-workgroup ordered compaction at every round, 280 MB of LM state sized once).  Size-independent properties."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 1_000_000
+    g = torch.Generator(device=DEV).manual_seed(9)
+    lo = torch.tensor([l[0] for l in O(robot).actuated_joints_limits], device=DEV)
+    hi = torch.tensor([l[1] for l in O(robot).actuated_joints_limits], device=DEV)
+    q = lo + (hi - lo) * torch.rand((n, 7), generator=g, device=DEV)
+    poses = robot.forward_kinematics(q)
+    sol, valid, stats = eng.generate_exact(poses, (1, 3, 10), 1e-3, 0.01, return_stats=True)
+    assert sol.shape == (n, 7) and valid.shape == (n,) and valid.dtype == torch.bool
+    assert int(stats[0, 0]) == n and int(stats[1, 0]) == n - int(stats[0, 3]) and int(stats[2, 0]) == int(stats[1, 0]) - int(stats[1, 3])
+    assert int(valid.sum()) == int(stats[:, 3].sum()) and int(stats[:, 1].sum()) > 13_000_000
+    assert bool((sol[~valid] == 0).all())  # unsolved rows stay 0 (ikflow_solver.py:197)
+    if int(valid.sum()) > 0:
+        pe, re = eng.pose_error(sol[valid], poses[valid])
+        assert bool((pe < 1e-3).all()) and bool((re < 0.01).all())
+        assert bool(((sol[valid] >= lo) & (sol[valid] <= hi)).all())
+    # the solved poses, checked independently of the kernels that flagged them (oracle FK on the CPU)
+    idx = torch.nonzero(valid)[:200, 0].cpu()
+    if idx.numel():
+        pe_ref, re_ref = ko.calculate_pose_error(robot, sol[idx.to(DEV)].cpu(), poses[idx.to(DEV)].cpu())
+        assert (pe_ref < 1e-3 * 1.01).all() and (re_ref < 0.01 * 1.05).all()
