@@ -62,6 +62,16 @@ def test_cpp_client_of_the_cabi(tmp_path):
     assert np.abs(fk[:, :3] - fk_ref[:, :3].numpy()).max() <= 2e-6
     pe_ref, re_ref = ko.calculate_pose_error(robot, torch.from_numpy(q), poses)
     assert np.abs(pe - pe_ref.numpy()).max() <= 2e-6 and np.abs(re - re_ref.numpy()).max() <= 3e-5
+    # exact IK from C++: ikf_refine_exact on the approximate solutions (the program itself checks that ikf_generate_exact with a C
+    # latent callback gives the identical result); oracle = one _generate_exact_ik_solutions round on the SAME seeds, LM in fp64
+    q2 = out[n * 16 : n * 23].reshape(n, 7)
+    valid = out[n * 23 : n * 24] > 0.5
+    assert "exact IK" in r.stdout
+    ref_sol, ref_valid = ko.exact_round(robot, torch.from_numpy(q.copy()), poses, 1, 0.05, 0.3, lm_dtype=torch.float64)
+    assert (torch.from_numpy(valid) == ref_valid).float().mean().item() >= 0.98
+    both = torch.from_numpy(valid) & ref_valid
+    assert 0 < int(both.sum()) and np.abs(q2[both.numpy()] - ref_sol[both].numpy()).max() <= 5e-6
+    assert not q2[~valid].any()
 
 
 def test_ikfbin_descriptor_layout_matches_header():
