@@ -246,7 +246,7 @@ def live_profile(kernel_substr="k_flow_gemm<"):
         d = tempfile.mkdtemp(prefix="ikf_prof_", dir="/tmp")
         sub[3], sub[5] = steps, warmup
         subprocess.run([exe] + flags + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + sub, cwd="/tmp",
-                       env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                       env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
         return d
 
     per_counter = {}
