@@ -804,6 +804,46 @@ def test_exact_ik_seeded_is_row_exact_against_the_oracle(which, pos_thr, rot_thr
     assert abs(int(stats[:, 3].sum()) - n_ref[0]) <= int(band.sum())
 
 
+def _random_exact_configs(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        rc = tuple(int(v) for v in rng.integers(1, 13, size=int(rng.integers(1, 5))))
+        out.append(dict(which=str(rng.choice(["panda", "fetch", "fetch_arm"])), n=int(rng.choice([1, 2, 50, 333, 1000, 2500])), rc=rc,
+                        pos_thr=float(rng.choice([5e-4, 1e-3, 5e-3])), rot_thr=float(rng.choice([0.01, 0.05, 0.1])), seed=int(rng.integers(0, 1000))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_exact_configs(int(os.environ.get("IKF_FUZZ_EXACT_COUNT", "16")), int(os.environ.get("IKF_FUZZ_SEED", "20260928"))),
+                         ids=lambda c: "-".join(str(v) for v in c.values()).replace(" ", ""))
+def test_exact_ik_seeded_random_schedules(cfg):
+    """The seeded exact-IK comparison over random robots, pose counts, repeat_counts schedules (1..4 rounds of 1..12 repeats; the
+    reference accepts any tuple, ikflow_solver.py:351) and thresholds - same band rule as the n = 4096 test above."""
+    from ikflow_amd.engine import kinematics_engine_for
+    from ikflow_amd.robots import get_robot
+
+    robot = get_robot(cfg["which"])
+    n, rc, pos_thr, rot_thr = cfg["n"], cfg["rc"], cfg["pos_thr"], cfg["rot_thr"]
+    q_true, poses = reachable_poses(robot, n, cfg["seed"])
+    tables = _seed_tables(robot, q_true, rc, cfg["seed"] + 1)
+    ref_sol, ref_valid, margins = ko.generate_exact_ik_solutions_seeded(
+        robot, lambda rnd, idx: tables[rnd][:, idx, :].reshape(-1, robot.ndof).contiguous(), poses, rc, pos_thr, rot_thr,
+        lm_dtype=torch.float64, return_margins=True)
+    eng = kinematics_engine_for(robot, DEV)
+    dev_tables = [t.to(DEV) for t in tables]
+    sol, valid, stats = eng.generate_exact(poses.to(DEV), rc, pos_thr, rot_thr, return_stats=True,
+                                           seed_fn=lambda rnd, idx, repeat: dev_tables[rnd][:, idx, :].reshape(-1, robot.ndof).contiguous())
+    sol, valid = sol.cpu(), valid.cpu()
+    clear = ~((margins[:, 0] <= 1e-4 * pos_thr + 5e-7) | (margins[:, 1] <= 1e-4 * rot_thr + 6e-7 / rot_thr))
+    assert int((~clear).sum()) <= max(2, 0.03 * n)
+    assert torch.equal(valid[clear], ref_valid[clear])
+    both = clear & valid & ref_valid
+    if bool(both.any()):
+        assert (sol[both] - ref_sol[both]).abs().max().item() <= 5e-6
+    assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
+    assert int(stats[0, 0]) == n and int(valid.sum()) == int(stats[: len(rc), 3].sum())
+
+
 def test_refine_exact_one_round_and_large_compaction():
     """ikf_refine_exact = one _generate_exact_ik_solutions call (:119-247) given its flow output; then the multi-workgroup
     ordered compaction (n > 32768) through a 100k-pose seeded call whose second round must see exactly the unsolved poses
