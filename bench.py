@@ -413,6 +413,11 @@ def run_cells(solver, eng, robot, layout, dev, precision):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# tests only (tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu): IKF_BENCH_TEST_BACKEND=gloo runs the N>1 path - row shards,
+# side-stream all-gather, fence, max over ranks - with the real engine and all ranks sharing cuda:0; the line says so and claims nothing
+TEST_BACKEND = os.environ.get("IKF_BENCH_TEST_BACKEND", "")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -427,8 +432,12 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if TEST_BACKEND:  # tests only: every rank on cuda:0 of a one-GPU box, gloo instead of RCCL (RCCL refuses two ranks on one device)
+            local_rank = 0
+            dist.init_process_group(TEST_BACKEND)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -555,6 +564,9 @@ def main():
                       "N=1 run; the N>1 path (row shards, one all_gather_into_tensor per step on a side stream) is covered by "
                       "gloo world-2 tests on CPU; no multi-GPU curve has been measured by the builder (8-GPU runs are the driver's)"),
     }
+    if TEST_BACKEND:
+        out["test_backend"] = f"{TEST_BACKEND}: all {world} ranks share cuda:0 - a test of the N>1 code path, NOT a measurement"
+        out["metric"] = "TEST RUN (ranks share one GPU): no throughput claim"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             name = MODEL_DESCRIPTIONS[args.model]["robot_name"]

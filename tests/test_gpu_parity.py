@@ -1245,3 +1245,29 @@ def test_exact_ik_one_million_poses():
     if idx.numel():
         pe_ref, re_ref = ko.calculate_pose_error(robot, sol[idx.to(DEV)].cpu(), poses[idx.to(DEV)].cpu())
         assert (pe_ref < 1e-3 * 1.01).all() and (re_ref < 0.01 * 1.05).all()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 path with the REAL engine: two ranks under torch.distributed.run, both on cuda:0, gloo in place of RCCL
+    (IKF_BENCH_TEST_BACKEND; RCCL refuses two ranks on one device) - row shards, side-stream all_gather_into_tensor behind an event,
+    fence, max over ranks, own shard at its rank offset (asserted inside bench.py), one JSON line from rank 0."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, IKF_BENCH_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "1024"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048 and out["scaling"] == "weak" and "test_backend" in out
+    assert out["value"] > 0 and abs(out["value"] - 2048 * 4 / (out["ms_per_step"] * 4e-3)) <= 1e-6 * out["value"]
+    assert "cpu_baseline" not in out and "cells" not in out["extra"]  # rank-0-at-N=1-only legs stay out of an N>1 line
