@@ -144,3 +144,62 @@ def test_sharded_solver_entry_points_gloo(world, n):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _worker_real_solver(rank, world, port, n, q):
+    """Both ranks on cuda:0 of the one-GPU box, gloo in place of RCCL: the real IKFlowSolver behind the sharded entry points."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import latents, reachable_poses, tiny_model
+    from ikflow_amd.dist import sharded_generate_exact_ik_solutions, sharded_generate_ik_solutions
+    from ikflow_amd.ikflow_solver import IKFlowSolver
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = "cuda:0"
+        robot, hp, lay, sd = tiny_model(seed=4)
+        s = IKFlowSolver(hp, robot)
+        s.load_state_dict_tensors(sd)
+        q_true, poses = reachable_poses(robot, n, 5)
+        poses, lat = poses.to(dev), latents(n, lay.dim, 6).to(dev)
+        single = s.generate_ik_solutions(poses, latent=lat)
+        # a shard of n/2 rows may take another tile shape than the n-row call (other summation order): equal to fp32 rounding
+        close = lambda a, b: float((a - b).abs().max()) <= 1e-5
+        ok = [close(sharded_generate_ik_solutions(s, poses, latent=lat), single)]
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        drawn = sharded_generate_ik_solutions(s, poses)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed(77)
+        ok.append(close(drawn, s.generate_ik_solutions(poses)))
+        # exact IK: retry rounds are per pose, shards never interact; every valid row meets the thresholds, invalid rows are zero
+        sol, valid = sharded_generate_exact_ik_solutions(s, poses, pos_error_threshold=5e-3, rot_error_threshold=0.1, repeat_counts=(1, 4))
+        ok.append(sol.shape == (n, robot.ndof) and valid.dtype == torch.bool and valid.shape == (n,))
+        ok.append(not bool(sol[~valid].any()))
+        if bool(valid.any()):
+            from ikflow_amd.evaluation_utils import pose_errors
+
+            pe, re = pose_errors(robot.forward_kinematics(sol[valid]), poses[valid])
+            ok.append(float(pe.max()) <= 5e-3 and float(re.max()) <= 0.1)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_entry_points_with_the_real_solver_two_ranks_one_gpu():
+    world, n = 2, 1501
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real_solver, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(all(ok) for _, ok in res), res
