@@ -15,6 +15,7 @@ SOURCES = ["flow_kernels.hip", "flow_fused.hip", "flow_split.hip", "kin_kernels.
 HEADERS = [os.path.join(CSRC, "ikf_internal.h"), os.path.join(CSRC, "flow_split_dma.inc"), os.path.join(_HERE, "..", "include", "ikflow_amd.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("IKF_HIPCC_FLAGS", "").split()  # probes only (e.g. -DIKF_NO_RANGE_FLAG); the shipped library is built without
 
 
 def _hipcc() -> str:
