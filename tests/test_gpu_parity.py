@@ -1271,3 +1271,14 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2048 and out["scaling"] == "weak" and "test_backend" in out
     assert out["value"] > 0 and abs(out["value"] - 2048 * 4 / (out["ms_per_step"] * 4e-3)) <= 1e-6 * out["value"]
     assert "cpu_baseline" not in out and "cells" not in out["extra"]  # rank-0-at-N=1-only legs stay out of an N>1 line
+
+
+def test_repeated_interleaved_calls_are_bit_identical():
+    """tools/determinism_soak.py, short form: the same call repeated while other batch sizes run in between (the engine's buffers are
+    shared between sizes) returns identical bits - approximate IK on every tile path in both precisions, and exact IK."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_soak.py"), "6"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
