@@ -710,7 +710,6 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
   constexpr int KQ4 = BK / 4;           // float4 per tile row
   constexpr int NFA = BM * KQ4 / NT;    // float4 of the A tile per thread per stage
   constexpr int STAGE = BM * LDK;       // only A rows are staged through LDS
-  constexpr int LDT = BN + 4;
   static_assert(BM * KQ4 % NT == 0 && NFA >= 1, "tile/threads mismatch");
   static_assert(KKG == 2, "the iteration below is written for two MFMA groups per wave per tile");
   static_assert(skinny_lds<NH>() >= sizeof(float) * 2 * STAGE, "the two A stages must fit");
