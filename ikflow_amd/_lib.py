@@ -75,6 +75,7 @@ SIGNATURES = {
     "ikf_weights_loaded": (C.c_int, [C.c_void_p]),
     "ikf_reserve": (C.c_int, [C.c_void_p, C.c_int64]),
     "ikf_reserve_exact": (C.c_int, [C.c_void_p, C.c_int64, C.c_int]),
+    "ikf_set_exact_upfront_rows": (C.c_int, [C.c_void_p, C.c_int64]),
     "ikf_generate_approx": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_void_p],

@@ -86,6 +86,7 @@ struct ikf_model {
   float* hB = nullptr;
   // exact-IK scratch
   long long exact_rows = 0, exact_poses = 0;
+  long long exact_upfront_rows = 32LL << 20;  // ikf_set_exact_upfront_rows
   float* ex_q = nullptr;          // [rows][ndof]
   uint8_t* ex_row_valid = nullptr;  // [rows]
   int* ex_pose_idx = nullptr;     // [poses]
@@ -122,6 +123,29 @@ static hipError_t stream_enter(ikf_model* m, hipStream_t s) {
   if (m->tail_valid && s != m->tail_stream) return hipStreamWaitEvent(s, m->tail_event, 0);
   return hipSuccess;
 }
+static hipError_t stream_leave(ikf_model* m, hipStream_t s);
+// Records the handle's tail event behind whatever a call has enqueued, on EVERY exit path (an error return in the middle of
+// a call leaves kernels in flight that still use the shared scratch; the next call on another stream must wait for them).
+struct StreamScope {
+  ikf_model* m;
+  hipStream_t s;
+  bool armed = false;
+  StreamScope(ikf_model* m_, hipStream_t s_) : m(m_), s(s_) {}
+  hipError_t enter() {
+    hipError_t e = stream_enter(m, s);
+    armed = (e == hipSuccess);
+    return e;
+  }
+  hipError_t leave() {  // the success path: reports the record's own status
+    armed = false;
+    return stream_leave(m, s);
+  }
+  ~StreamScope() {
+    if (armed) (void)stream_leave(m, s);
+  }
+  StreamScope(const StreamScope&) = delete;
+  StreamScope& operator=(const StreamScope&) = delete;
+};
 static hipError_t stream_leave(ikf_model* m, hipStream_t s) {
   if (!m->tail_event) {
     hipError_t e = hipEventCreateWithFlags(&m->tail_event, hipEventDisableTiming);
@@ -292,6 +316,12 @@ static ikf_status build_split_weights(ikf_model* m) {
   if (m->split_arena || d.n_hidden < 2 || W % 128 != 0 || !m->loaded) return IKF_OK;
   const size_t per = (size_t)W * W * 2;  // uint16 elements per layer
   const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
+  // the range word is shared with the activation guard: take what is pending out of it so that only the weight packs below
+  // can set it, and put the pending bits back afterwards (they belong to ikf_split_overflow_pending)
+  int pending_flag = 0;
+  IKF_HIP(hipDeviceSynchronize());
+  IKF_HIP(hipMemcpy(&pending_flag, m->d_split_flag, sizeof(int), hipMemcpyDeviceToHost));
+  IKF_HIP(hipMemset(m->d_split_flag, 0, sizeof(int)));
   IKF_HIP(hipMalloc(&m->split_arena, sizeof(uint16_t) * per * n_layers));
   m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
   size_t li = 0;
@@ -318,8 +348,8 @@ static ikf_status build_split_weights(ikf_model* m) {
   // a weight beyond the f16 range cannot be split: the mode is refused (the f32 path is unaffected)
   int wflag = 0;
   IKF_HIP(hipMemcpy(&wflag, m->d_split_flag, sizeof(int), hipMemcpyDeviceToHost));
+  IKF_HIP(hipMemcpy(m->d_split_flag, &pending_flag, sizeof(int), hipMemcpyHostToDevice));
   if (wflag != 0) {
-    IKF_HIP(hipMemset(m->d_split_flag, 0, sizeof(int)));
     (void)hipFree(m->split_arena); m->split_arena = nullptr;
     if (m->split_frag_arena) { (void)hipFree(m->split_frag_arena); m->split_frag_arena = nullptr; }
     m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
@@ -490,13 +520,16 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
   if (m->split_frag_arena) { (void)hipFree(m->split_frag_arena); m->split_frag_arena = nullptr; }
   m->w_mid_split.assign((size_t)2 * NB * 3, nullptr);
   m->w_mid_split_frag.assign((size_t)2 * NB * 3, nullptr);
-  m->loaded = true;
-  if (m->precision == 1) {
-    ikf_status sst = build_split_weights(m);
-    if (sst != IKF_OK) return sst;
-  }
+  // The f32 images first and unconditionally: whatever happens to the f16x3 images below, every batch size of the f32 path
+  // must see the NEW weights (the <= 512-row kernels read the fragment-major copy).
+  m->loaded = false;
   ikf_status fst = build_frag_weights(m);
   if (fst != IKF_OK) return fst;
+  m->loaded = true;
+  if (m->precision == 1) {
+    ikf_status sst = build_split_weights(m);  // refusal: precision falls back to f32, the handle stays usable
+    if (sst != IKF_OK) return sst;
+  }
   return IKF_OK;
 }
 
@@ -524,21 +557,40 @@ static ikf_status ensure_scratch(ikf_model* m, long long rows) {
   return IKF_OK;
 }
 
-static ikf_status ensure_exact(ikf_model* m, long long poses, long long rows) {
-  if (poses > m->exact_poses || rows > m->exact_rows) {
-    const long long np = poses > m->exact_poses ? poses : m->exact_poses;
-    const long long nr = rows > m->exact_rows ? rows : m->exact_rows;
-    free_exact(m);
-    IKF_HIP(hipMalloc(&m->ex_q, sizeof(float) * (size_t)nr * m->dims.ndof));
-    IKF_HIP(hipMalloc(&m->ex_row_valid, (size_t)nr));
-    IKF_HIP(hipMalloc(&m->ex_pose_idx, sizeof(int) * (size_t)np));
-    IKF_HIP(hipMalloc(&m->ex_solved, (size_t)np));
-    IKF_HIP(hipMalloc(&m->ex_block_scratch, sizeof(int) * 2 * (size_t)(compact_blocks(np) + 1)));
-    m->exact_poses = np;
-    m->exact_rows = nr;
-  }
+// exact-IK state: per-pose buffers (active list, solved flags, compaction scratch) and per-row buffers (q, row validity) grow
+// independently - the row buffers carry nothing from one retry round to the next, so they may be regrown between rounds
+// (right after the round's count has been read, i.e. with the stream idle) without touching the active-pose list.
+static ikf_status ensure_exact_poses(ikf_model* m, long long poses) {
+  if (poses <= m->exact_poses) return IKF_OK;
+  if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
+  if (m->ex_solved) (void)hipFree(m->ex_solved);
+  if (m->ex_block_scratch) (void)hipFree(m->ex_block_scratch);
+  m->ex_pose_idx = nullptr; m->ex_solved = nullptr; m->ex_block_scratch = nullptr;
+  m->exact_poses = 0;
+  IKF_HIP(hipMalloc(&m->ex_pose_idx, sizeof(int) * (size_t)poses));
+  IKF_HIP(hipMalloc(&m->ex_solved, (size_t)poses));
+  IKF_HIP(hipMalloc(&m->ex_block_scratch, sizeof(int) * 2 * (size_t)(compact_blocks(poses) + 1)));
+  m->exact_poses = poses;
   return IKF_OK;
 }
+static ikf_status ensure_exact_rows(ikf_model* m, long long rows) {
+  if (rows <= m->exact_rows) return IKF_OK;
+  if (m->ex_q) (void)hipFree(m->ex_q);
+  if (m->ex_row_valid) (void)hipFree(m->ex_row_valid);
+  m->ex_q = nullptr; m->ex_row_valid = nullptr;
+  m->exact_rows = 0;
+  IKF_HIP(hipMalloc(&m->ex_q, sizeof(float) * (size_t)rows * m->dims.ndof));
+  IKF_HIP(hipMalloc(&m->ex_row_valid, (size_t)rows));
+  m->exact_rows = rows;
+  return IKF_OK;
+}
+static ikf_status ensure_exact(ikf_model* m, long long poses, long long rows) {
+  ikf_status st = ensure_exact_poses(m, poses);
+  return st != IKF_OK ? st : ensure_exact_rows(m, rows);
+}
+// Worst-case row state (every pose unsolved in the round with the largest repeat count) is reserved up front only while it is
+// small (ikf_set_exact_upfront_rows, default 32 Mi rows); beyond that a call starts with round 0's rows and grows per round from the measured survivor count, so a
+// large n with a big last-round repeat but few survivors neither allocates nor is rejected for the worst case.
 
 extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_reserve: null model");
@@ -584,6 +636,12 @@ static const float* chain_lo(const ikf_model* m) {
 }
 static const float* chain_hi(const ikf_model* m) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, hi));
+}
+
+// fragment-major image of hidden layer l of subnet si, or null (not built for this width / not loaded)
+static const float* frag_image(const ikf_model* m, int si, int l) {
+  const size_t i = (size_t)si * 3 + l;
+  return i < m->w_mid_frag.size() ? m->w_mid_frag[i] : nullptr;
 }
 
 static bool fused_ok(const ikf_model* m) {
@@ -635,7 +693,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
     const bool one_launch = !split && (m->fuse_entry == 2 || (m->fuse_entry == 1 && cfg == fused_skinny32_cfg())) &&
                             entry_gemm_ok(cfg, nr, d.width, d.D, pend.P ? pend.n_out : 0) &&
-                            m->w_mid_frag[(size_t)(2 * b + which - 1) * 3] != nullptr;
+                            frag_image(m, 2 * b + which - 1, 0) != nullptr;
     if (!one_launch) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
     float* cur = m->hA;
     float* nxt = m->hB;
@@ -652,7 +710,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
         IKF_HIP(launch_split_gemm(last, scfg, sg, s));
       } else {
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
-        g.Wf = m->w_mid_frag[(size_t)(2 * b + which - 1) * 3 + l];
+        g.Wf = frag_image(m, 2 * b + which - 1, l);
         if (l == 0 && one_launch) IKF_HIP(launch_entry_gemm(w.n_x + d.n_pose, last, cfg, e, g, s));
         else IKF_HIP(launch_flow_gemm(last, cfg, g, s));
       }
@@ -750,10 +808,11 @@ extern "C" ikf_status ikf_generate_approx(ikf_model* m, const float* d_poses, in
   IKF_ON_DEVICE(m)
   PoseSource ps{d_poses, nullptr, pose_broadcast ? 1 : (long long)n, 7, softflow_scale};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  IKF_HIP(stream_enter(m, s));
+  StreamScope scope(m, s);
+  IKF_HIP(scope.enter());
   st = run_flow_guarded(m, ps, d_latent, n, clamp_to_limits, d_q_out, s);
   if (st != IKF_OK) return st;
-  IKF_HIP(stream_leave(m, s));
+  IKF_HIP(scope.leave());
   return IKF_OK;
 }
 
@@ -921,13 +980,17 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
   if (h_stats) memset(h_stats, 0, sizeof(int64_t) * 4 * n_rounds);
   if (n == 0) return IKF_OK;
   if (!d_target_poses || !d_q_out || !d_valid_out) return fail(IKF_ERR_NULL_POINTER, who + ": null device pointer");
-  if (n > 0x7fffffffLL / 64 || n * (long long)max_repeat > 0x7fffffffLL) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n too large");
+  if (n > 0x7fffffffLL / 64 || n * (long long)repeat_counts[0] > 0x7fffffffLL) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n too large");
   const int ndof = m->dims.ndof;
-  // the state of every round fits what round r could need at most (all n poses still unsolved): sized once, before any
-  // work is enqueued, so no allocation (= device-wide synchronisation) happens between the rounds
-  ikf_status st = ensure_exact(m, n, n * (long long)max_repeat);
+  // Row state: when the worst case of the schedule (all n poses still unsolved in the round with the largest repeat count) is
+  // small it is sized once, before any work is enqueued, so no allocation (= device-wide synchronisation) happens between the
+  // rounds; a larger worst case - or whatever ikf_reserve_exact has already provided - is not allocated for: the call
+  // starts with round 0's rows and each later round grows to its measured n_active * R if it has to.
+  const long long worst_rows = n * (long long)max_repeat;
+  ikf_status st = ensure_exact(m, n, worst_rows <= m->exact_upfront_rows ? worst_rows : n * (long long)repeat_counts[0]);
   if (st != IKF_OK) return st;
-  IKF_HIP(stream_enter(m, s));
+  StreamScope scope(m, s);
+  IKF_HIP(scope.enter());
 
   IKF_HIP(hipMemsetAsync(d_q_out, 0, sizeof(float) * (size_t)n * ndof, s));  // unsolved rows stay 0.0 (:197)
   IKF_HIP(hipMemsetAsync(d_valid_out, 0, (size_t)n, s));
@@ -945,6 +1008,11 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
       if (n_active == 0) break;  // everything converged (:383-385, :402-408)
     }
     const long long rows = n_active * R;
+    if (rows > 0x7fffffffLL) return fail(IKF_ERR_BAD_ARGUMENT, who + ": a retry round has more than 2^31 - 1 rows");
+    if (rows > m->exact_rows) {  // r > 0 only (round 0 was sized above); the stream is idle: the count was just read
+      st = ensure_exact_rows(m, rows);
+      if (st != IKF_OK) return st;
+    }
     if (seed_fn) {
       const float* d_seeds = seed_fn(user, r, n_active, R, m->ex_pose_idx, ndof);
       if (!d_seeds) return fail(IKF_ERR_NULL_POINTER, who + ": seed_fn returned null");
@@ -975,7 +1043,7 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
     IKF_HIP(hipStreamSynchronize(s));
     h_stats[4 * (n_rounds - 1) + 3] = h_stats[4 * (n_rounds - 1) + 0] - *m->h_count;
   }
-  IKF_HIP(stream_leave(m, s));
+  IKF_HIP(scope.leave());
   return IKF_OK;
 }
 
@@ -1025,6 +1093,13 @@ extern "C" ikf_status ikf_reserve_exact(ikf_model* m, int64_t max_poses, int max
   return ensure_exact(m, max_poses, max_poses * (long long)max_repeat);
 }
 
+extern "C" ikf_status ikf_set_exact_upfront_rows(ikf_model* m, int64_t max_rows) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_exact_upfront_rows: null model");
+  if (max_rows < 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_exact_upfront_rows: max_rows must be >= 0");
+  m->exact_upfront_rows = max_rows;
+  return IKF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // measurement hook
 // ---------------------------------------------------------------------------------------------------------------
@@ -1049,7 +1124,7 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
     // the contraction that reads its A operand from HBM and reduces the last Linear in its epilogue (h -> partials)
     g.M = (int)rows; g.N = m->dims.width; g.K = m->dims.width; g.slope = m->dims.slope;
     g.A = m->hA; g.W = w.w_mid[m->dims.n_hidden - 2]; g.bias = w.b_mid[m->dims.n_hidden - 2];
-    g.Wf = m->w_mid_frag.empty() ? nullptr : m->w_mid_frag[(size_t)(m->dims.n_hidden - 2)];
+    g.Wf = frag_image(m, 0, m->dims.n_hidden - 2);
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = m->chunk_rows * IKF_PSTRIDE;
   }
   auto launch = [&]() -> hipError_t {

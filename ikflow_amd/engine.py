@@ -162,6 +162,10 @@ class Engine:
         """Pre-size the exact-IK state (max_poses * max_repeat LM rows) so that generate_exact allocates nothing."""
         _check(self.lib.ikf_reserve_exact(self._h, int(max_poses), int(max_repeat)))
 
+    def set_exact_upfront_rows(self, max_rows: int) -> None:
+        """Largest worst-case exact-IK row state a call may reserve up front (0: always grow per retry round)."""
+        _check(self.lib.ikf_set_exact_upfront_rows(self._h, int(max_rows)))
+
     PRECISIONS = {"f32": 0, "f16x3": 1}
 
     def set_precision(self, mode: str) -> None:

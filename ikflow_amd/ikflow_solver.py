@@ -112,7 +112,14 @@ class IKFlowSolver:
             if self._state_dict_np is not None:
                 eng.load_state_dict(self._state_dict_np)
             if self._precision != "f32":
-                eng.set_precision(self._precision)
+                try:
+                    eng.set_precision(self._precision)
+                except Exception:
+                    # the engine refused the mode for these weights (e.g. a hidden weight beyond the f16 range) and stays
+                    # on f32: the solver follows it, so solver and engine never disagree, and reports the refusal once
+                    self._precision = "f32"
+                    self._engine = eng
+                    raise
             self._engine = eng
         return self._engine
 
@@ -120,9 +127,9 @@ class IKFlowSolver:
         """Arithmetic of the hidden Linear contractions: "f32" (exact f32 MFMA, default) or "f16x3" (error-compensated
         f16 split, measured at least as accurate against fp64; see include/ikflow_amd.h ikf_set_precision)."""
         assert mode in ("f32", "f16x3"), mode
-        self._precision = mode
         if self._engine is not None:
-            self._engine.set_precision(mode)
+            self._engine.set_precision(mode)  # EngineError when the mode is refused: the solver then keeps its previous mode
+        self._precision = mode
 
     def _ensure_initialized(self, allow_uninitialized: bool):
         """The reference runs its randomly initialised nn_model when allow_uninitialized=True
@@ -256,5 +263,8 @@ class IKFlowSolver:
         validate_state_dict(self._layout, sd)  # RuntimeError like nn.Module.load_state_dict on a bad file
         self._state_dict_np = sd
         if self._engine is not None:
-            self._engine.load_state_dict(sd)
+            try:
+                self._engine.load_state_dict(sd)
+            finally:  # an f16x3 handle refuses out-of-range weights by falling back to f32: the solver follows its engine
+                self._precision = self._engine.precision
         self._model_weights_loaded = True

@@ -69,6 +69,8 @@ MODEL_DESCRIPTIONS: Dict[str, Dict] = {
     "fetch_full_temp_nsc_tpm": dict(nb_nodes=12, dim_latent_space=8, coeff_fn_config=3, coeff_fn_internal_size=1024, rnvp_clamp=2.5, robot_name="fetch"),
     "fetch__large__ns183_9.75m": dict(nb_nodes=16, dim_latent_space=8, coeff_fn_config=3, coeff_fn_internal_size=1024, rnvp_clamp=2.5, robot_name="fetch"),
     "fetch_arm__large__mh186_9.25m": dict(nb_nodes=16, dim_latent_space=10, coeff_fn_config=3, coeff_fn_internal_size=1024, rnvp_clamp=2.5, robot_name="fetch_arm"),
+    # ikflow/model_descriptions.yaml:90-97.  The robot itself is data: Robot.from_urdf / register_robot_urdf (robots.py)
+    "rizon4__snowy-brook-208__global_step=2.75M": dict(nb_nodes=12, dim_latent_space=7, coeff_fn_config=3, coeff_fn_internal_size=1024, rnvp_clamp=2.5, robot_name="rizon4"),
 }
 
 

@@ -20,6 +20,7 @@ MODEL_WEIGHT_FILENAMES = {
     "fetch_full_temp_nsc_tpm": "fetch__sleek-microwave-65__global_step%3D9.25M.pkl",
     "fetch__large__ns183_9.75m": "fetch__northern-sea-183__global_step%3D9.75M.pkl",
     "fetch_arm__large__mh186_9.25m": "fetch_arm__major-hill-186__global_step%3D9.25M.pkl",
+    "rizon4__snowy-brook-208__global_step=2.75M": "rizon4__snowy-brook-208__global_step%3D2.75M.pkl",
 }
 
 

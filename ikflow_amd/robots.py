@@ -72,6 +72,96 @@ class Robot:
         assert all(l is not None for l in lims), "every actuated joint needs limits"
         self._limits: List[Tuple[float, float]] = [(float(l[0]), float(l[1])) for l in lims]
 
+    # -- construction from data -----------------------------------------------------------------------
+    @classmethod
+    def from_urdf(cls, path_or_xml: str, base_link: Optional[str] = None, end_effector_link: Optional[str] = None,
+                  name: Optional[str] = None, continuous_limits: Tuple[float, float] = (-math.pi, math.pi)) -> "Robot":
+        """Build the base->end-effector chain of a robot from its URDF (a file path or the XML text): a new robot is data,
+        not code.  This is what ``jrl.Robot`` does with the URDFs it ships (``jrl/robots.py``; the package is absent here).
+
+        The kinematic tree is read from every ``<joint>``'s ``<parent link>`` / ``<child link>``; the chain is the unique
+        path from ``end_effector_link`` up to ``base_link`` (joints on other branches - fingers, head, wheels - are not on
+        it).  Per joint: ``<origin xyz rpy>`` (missing = identity), ``<axis xyz>`` (missing = 1 0 0, the URDF default),
+        ``<limit lower upper>``; ``continuous`` joints get ``continuous_limits`` (jrl: [-pi, pi]); ``revolute`` /
+        ``prismatic`` joints are actuated, ``fixed`` joints stay on the chain and are folded into their neighbours by the
+        engine (``ikflow_amd.engine.fold_chain``).  ``mimic`` joints on the chain and ``floating`` / ``planar`` joints are
+        refused: the engine has one scalar per actuated joint.
+
+        When NO joint of the document names a parent / child (a bare list of ``<joint>`` elements, as test fixtures keep
+        them) and both link arguments are None, the document order is the chain."""
+        import os
+        import xml.etree.ElementTree as ET
+
+        text = path_or_xml
+        if "<" not in path_or_xml:
+            assert os.path.isfile(path_or_xml), f"URDF file '{path_or_xml}' was not found"
+            with open(path_or_xml, "r") as f:
+                text = f.read()
+        root = ET.fromstring(text)
+        assert root.tag == "robot", f"not a URDF: the root element is <{root.tag}>, expected <robot>"
+        kinds = {"fixed": JOINT_FIXED, "revolute": JOINT_REVOLUTE, "continuous": JOINT_REVOLUTE, "prismatic": JOINT_PRISMATIC}
+
+        def floats(s: Optional[str], default):
+            if s is None:
+                return tuple(default)
+            v = tuple(float(x) for x in s.split())
+            assert len(v) == 3, f"expected three numbers, got '{s}'"
+            return v
+
+        def make(j) -> Joint:
+            jname, typ = j.get("name"), j.get("type")
+            if typ not in kinds:
+                raise ValueError(f"joint '{jname}' has type '{typ}': only fixed / revolute / continuous / prismatic joints can be on the chain")
+            if j.find("mimic") is not None and typ != "fixed":
+                raise ValueError(f"joint '{jname}' mimics another joint: not supported on the base->end-effector chain")
+            origin, axis, limit = j.find("origin"), j.find("axis"), j.find("limit")
+            lim = None
+            if typ == "continuous":
+                lim = (float(continuous_limits[0]), float(continuous_limits[1]))
+            elif typ in ("revolute", "prismatic"):
+                if limit is None or limit.get("lower") is None or limit.get("upper") is None:
+                    raise ValueError(f"joint '{jname}' ({typ}) has no <limit lower=.. upper=..>")
+                lim = (float(limit.get("lower")), float(limit.get("upper")))
+                assert lim[0] <= lim[1], f"joint '{jname}': lower limit above upper limit"
+            ax = floats(axis.get("xyz") if axis is not None else None, (1.0, 0.0, 0.0))
+            if typ != "fixed":
+                assert any(abs(a) > 0 for a in ax), f"joint '{jname}' has a zero axis"
+            return Joint(jname, kinds[typ], floats(origin.get("xyz") if origin is not None else None, (0.0, 0.0, 0.0)),
+                         floats(origin.get("rpy") if origin is not None else None, (0.0, 0.0, 0.0)),
+                         ax if typ != "fixed" else (0.0, 0.0, 1.0), lim)
+
+        jelems = root.findall("joint")
+        assert jelems, "the URDF has no <joint> elements"
+        has_tree = any(j.find("parent") is not None or j.find("child") is not None for j in jelems)
+        if not has_tree:
+            assert base_link is None and end_effector_link is None, (
+                "this URDF names no parent / child links, so base_link / end_effector_link cannot be resolved")
+            chain = [make(j) for j in jelems]
+        else:
+            assert base_link is not None and end_effector_link is not None, "base_link and end_effector_link are required"
+            by_child = {}
+            for j in jelems:
+                par, chi = j.find("parent"), j.find("child")
+                assert par is not None and chi is not None, f"joint '{j.get('name')}' lacks <parent> or <child>"
+                c = chi.get("link")
+                assert c not in by_child, f"link '{c}' is the child of two joints: not a tree"
+                by_child[c] = (par.get("link"), j)
+            links = {l.get("name") for l in root.findall("link")} | set(by_child) | {p for p, _ in by_child.values()}
+            assert base_link in links, f"base_link '{base_link}' is not a link of this URDF"
+            assert end_effector_link in links, f"end_effector_link '{end_effector_link}' is not a link of this URDF"
+            rev, link, seen = [], end_effector_link, set()
+            while link != base_link:
+                if link not in by_child or link in seen:
+                    raise ValueError(f"'{end_effector_link}' is not a descendant of '{base_link}' in this URDF")
+                seen.add(link)
+                parent, j = by_child[link]
+                rev.append(make(j))
+                link = parent
+            chain = rev[::-1]
+        robot = cls(name if name is not None else root.get("name", "robot"), chain)
+        assert robot.ndof >= 1, "the chain has no actuated joint"
+        return robot
+
     # -- description ---------------------------------------------------------------------------------
     @property
     def name(self) -> str:
@@ -319,10 +409,29 @@ def Fetch() -> Robot:
 
 _ROBOTS = {"panda": Panda, "fetch_arm": FetchArm, "fetch": Fetch}
 
+# Robots whose released model is registered (ikflow/model_descriptions.yaml) but whose chain this repository does not
+# carry: their URDF lives in jrl, which is not on this machine, and nothing the reference holds pins a chain typed from
+# memory.  They are DATA: Robot.from_urdf(<file>, base_link, end_effector_link, name=<robot_name>), or
+# register_robot_urdf(...) once so that get_robot / get_ik_solver find them.  Link names as jrl uses them.
+URDF_ONLY_ROBOTS = {
+    "rizon4": dict(base_link="base_link", end_effector_link="flange", ndof=7),  # Flexiv Rizon 4: 7 revolute joints
+}
+
+
+def register_robot_urdf(robot_name: str, path_or_xml: str, base_link: str, end_effector_link: str) -> None:
+    """Make get_robot(robot_name) build the robot from this URDF (e.g. the Flexiv Rizon 4 description for 'rizon4')."""
+    _ROBOTS[robot_name] = lambda: Robot.from_urdf(path_or_xml, base_link, end_effector_link, name=robot_name)
+
 
 def get_robot(robot_name: str) -> Robot:
     """Mirror of ``jrl.robots.get_robot`` for the robots whose released models are on the hot path
     (ikflow/model_loading.py:81-83)."""
     if robot_name not in _ROBOTS:
+        if robot_name in URDF_ONLY_ROBOTS:
+            h = URDF_ONLY_ROBOTS[robot_name]
+            raise ValueError(
+                f"Robot '{robot_name}' has no built-in chain (its URDF ships with jrl, which is not available here): build it with "
+                f"Robot.from_urdf(<urdf>, '{h['base_link']}', '{h['end_effector_link']}', name='{robot_name}') and pass robot=..., or call "
+                f"register_robot_urdf('{robot_name}', <urdf>, '{h['base_link']}', '{h['end_effector_link']}') once")
         raise ValueError(f"Unable to find robot '{robot_name}' (available: {sorted(_ROBOTS)})")
     return _ROBOTS[robot_name]()

@@ -108,9 +108,15 @@ int ikf_weights_loaded(const ikf_model* m);
 /* Pre-size the flow scratch for batches of up to max_rows flow rows. */
 ikf_status ikf_reserve(ikf_model* m, int64_t max_rows);
 /* Pre-size the exact-IK state for calls of up to max_poses target poses with repeat counts up to max_repeat
- * (max_poses * max_repeat LM rows), so that ikf_generate_exact allocates nothing.  Without it the first call sizes the
- * state for its own worst case (n * max(repeat_counts) rows) before any work is enqueued. */
+ * (max_poses * max_repeat LM rows), so that ikf_generate_exact allocates nothing.  Without it a call sizes the row state
+ * for its own worst case (n * max(repeat_counts) rows) before any work is enqueued while that is at most 32 Mi rows; a
+ * larger worst case is not allocated for: the call starts with round 0's rows and a later round grows the state to its
+ * measured n_active * repeat rows (between rounds, where the host has just read the count and the stream is idle). */
 ikf_status ikf_reserve_exact(ikf_model* m, int64_t max_poses, int max_repeat);
+/* The largest worst-case row state (n * max(repeat_counts) rows) a call may reserve up front on its own; default 32 Mi
+ * rows.  0 = never reserve for the worst case: every call starts with round 0's rows and grows per round (memory-constrained
+ * callers).  Has no effect on what ikf_reserve_exact has already provided. */
+ikf_status ikf_set_exact_upfront_rows(ikf_model* m, int64_t max_rows);
 
 /* -- approximate IK: replaces IKFlowSolver._run_inference (ikflow_solver.py:85-110) ----------------------- */
 /* d_poses: [n x 7], or a single pose [7] when pose_broadcast != 0 (the `y.expand((n,7))` form, :333-336).

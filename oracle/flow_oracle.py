@@ -61,6 +61,10 @@ RELEASED = {
     "fetch_arm__large__mh186_9.25m": ("fetch_arm", 16, 10, 3, 1024, 2.5),  # yaml:56-63
     "tiny": ("panda", 3, 9, 2, 256, 2.5),  # ikflow/model.py:45-48, dim_latent_space default 9
 }
+# released hyper-parameters whose robot has no chain in oracle/robot_tables.py (the URDF ships with jrl, absent here)
+RELEASED_NO_CHAIN = {
+    "rizon4__snowy-brook-208__global_step=2.75M": ("rizon4", 12, 7, 3, 1024, 2.5),  # yaml:90-97
+}
 
 
 @dataclass(frozen=True)

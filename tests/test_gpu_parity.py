@@ -1036,6 +1036,101 @@ def test_f16x3_range_guard():
     assert s2.engine(DEV).precision == "f32"
 
 
+def test_reload_with_out_of_range_weight_in_f16x3_mode_keeps_every_batch_size_on_the_new_weights():
+    """A handle already in f16x3 mode is given a state dict with a hidden weight beyond the f16 range: the split images are
+    refused and the handle falls back to f32 - and the f32 path, at EVERY batch size (the <= 512-row kernels read the
+    fragment-major weight image, larger batches the row-major one), must run the NEW weights.  Also: an activation-overflow
+    bit left in the shared range word by an unguarded call must not make a later set_precision refuse valid weights."""
+    from ikflow_amd.engine import EngineError
+
+    robot, hp, lay, sd = tiny_model()
+    k = f"module_list.{lay.glow_module(0)}.subnet1.2.weight"
+    sd_bad = dict(sd)
+    sd_bad[k] = sd_bad[k].copy()
+    sd_bad[k][3, 5] = 1.0e5
+    _, poses = reachable_poses(robot, 700, 31)
+    lat = latents(700, lay.dim, 32)
+    want_new = fo.generate_ik_solutions_torch(sd_bad, lay, robot, poses, lat)
+    want_old = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
+    assert (want_new - want_old).abs().max().item() > 1e-3  # the two weight sets are distinguishable
+    for first_load_in_split_mode in (False, True):
+        s = IKFlowSolver(hp, robot)
+        if first_load_in_split_mode:  # the very first load of a handle that is already in f16x3 mode
+            s.load_state_dict_tensors(sd_bad)
+            s._precision = "f16x3"
+            with pytest.raises(EngineError, match="f16 range"):
+                s.engine(DEV)
+            assert s._precision == "f32"  # the solver follows the engine's refusal
+        else:
+            s.load_state_dict_tensors(sd)
+            s.set_precision("f16x3")
+            s.generate_ik_solutions(poses[:64].to(DEV), latent=lat[:64].to(DEV))
+            with pytest.raises(EngineError, match="f16 range"):
+                s.load_state_dict_tensors(sd_bad)
+            assert s._precision == "f32"
+        eng = s.engine(DEV)
+        assert eng.precision == "f32" and eng.weights_loaded
+        for n in (5, 200, 256, 300, 512, 700):  # 32x32 tiles, 32x64 tiles, large tiles
+            got = eng.generate_approx(poses[:n].to(DEV), lat[:n].to(DEV), True).cpu()
+            assert (got - want_new[:n]).abs().max().item() <= FLOW_TOL, (first_load_in_split_mode, n)
+    # a pending activation-overflow bit does not poison the weight check of a later mode switch
+    robot, hp, lay, sd = custom_model(nb_nodes=2, dim=7, n_hidden=3, width=256, seed=4)
+    g = lay.glow_module(1)
+    hot = dict(sd)
+    hot[f"module_list.{g}.subnet2.0.weight"] = hot[f"module_list.{g}.subnet2.0.weight"] * 4.0e5
+    hot[f"module_list.{g}.subnet2.0.bias"] = hot[f"module_list.{g}.subnet2.0.bias"] * 4.0e5
+    hot[f"module_list.{g}.subnet2.2.weight"] = hot[f"module_list.{g}.subnet2.2.weight"] / 4.0e5
+    s = _solver(robot, hp, hot)
+    s.set_precision("f16x3")
+    eng = s.engine(DEV)
+    eng.set_split_guard(False)
+    _, p2 = reachable_poses(robot, 300, 33)
+    s.generate_ik_solutions(p2.to(DEV), latent=latents(300, lay.dim, 34).to(DEV))  # leaves the overflow bit set
+    s.load_state_dict_tensors(sd)  # in-range weights, mode f16x3: must be accepted
+    assert eng.precision == "f16x3"
+    assert eng.split_overflow_pending()  # ... and the pending bit still belongs to its reader
+    eng.set_split_guard(True)
+    got = s.generate_ik_solutions(p2.to(DEV), latent=latents(300, lay.dim, 34).to(DEV)).cpu()
+    assert (got - fo.generate_ik_solutions_torch(sd, lay, robot, p2, latents(300, lay.dim, 34))).abs().max().item() <= FLOW_TOL
+    assert eng.split_fallback_count == 0
+
+
+def test_exact_ik_row_state_grows_per_round_and_error_exits_keep_the_stream_contract():
+    """(1) Without ikf_reserve_exact the row state of a call is what its rounds need; a schedule whose worst case is beyond the
+    up-front bound starts with round 0's rows and grows between rounds - results equal those of a reserved handle.
+    (2) A call that fails after work was enqueued (a latent callback that gives up in round 1) still records the handle's
+    tail event: a following call on ANOTHER stream waits for the first call's kernels (shared scratch) and is correct."""
+    robot, hp, lay, sd = tiny_model()
+    n = 3000
+    _, poses = reachable_poses(robot, n, 41)
+    P = poses.to(DEV)
+    rc = (1, 2, 4)
+    lats = [latents(n * r, lay.dim, 50 + i).to(DEV) for i, r in enumerate(rc)]
+    a = _solver(robot, hp, sd)
+    a.engine(DEV).reserve_exact(n, 4)
+    sol_a, val_a = a.engine(DEV).generate_exact(P, rc, 1e-3, 0.01, latents=lats)
+    b = _solver(robot, hp, sd)  # nothing reserved, and no up-front worst case: the row state grows between the rounds
+    b.engine(DEV).set_exact_upfront_rows(0)
+    sol_b, val_b = b.engine(DEV).generate_exact(P, rc, 1e-3, 0.01, latents=lats)
+    assert torch.equal(val_a, val_b) and torch.equal(sol_a, sol_b)
+    assert 0 < int(val_a.sum()) < n  # rounds 1 and 2 really ran
+
+    class GiveUp(Exception):
+        pass
+
+    eng = b.engine(DEV)
+    short = [lats[0], lats[1][:5]]  # round 1's latent is too short: the callback raises after round 0 was enqueued
+    s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    with torch.cuda.stream(s1):
+        with pytest.raises(AssertionError, match="must be at least"):
+            eng.generate_exact(P, rc[:2], 1e-3, 0.01, latents=short)
+    with torch.cuda.stream(s2):  # no host synchronisation in between
+        got = b.generate_ik_solutions(P, latent=lats[0])
+    torch.cuda.synchronize()
+    want = a.generate_ik_solutions(P, latent=lats[0])
+    assert torch.equal(got, want)
+
+
 def test_one_handle_called_from_two_streams():
     """The per-handle scratch is shared: a call arriving on another stream waits for the previous call's work
     (hipStreamWaitEvent).  Alternating streams without any host synchronisation must give the single-stream results."""

@@ -123,7 +123,10 @@ def test_released_hyper_parameters_and_layouts_agree(model_name):
     assert fo.OracleLayout.of(lp) == lo
     assert (lp.split1, lp.split2, lp.module_offset + 1) == (lo.len1, lo.len2, lo.first_block_module)
     assert lp.flops_per_solution() == lo.flops_per_solution()
-    assert sorted(pm.MODEL_DESCRIPTIONS) == sorted(n for n in fo.RELEASED if n != "tiny")
+    assert sorted(pm.MODEL_DESCRIPTIONS) == sorted([n for n in fo.RELEASED if n != "tiny"] + list(fo.RELEASED_NO_CHAIN))
+    for name, row in fo.RELEASED_NO_CHAIN.items():  # hyper-parameters only: the robot is data (Robot.from_urdf)
+        d = pm.MODEL_DESCRIPTIONS[name]
+        assert (d["robot_name"], d["nb_nodes"], d["dim_latent_space"], d["coeff_fn_config"], d["coeff_fn_internal_size"], d["rnvp_clamp"]) == row
 
 
 def test_work_figures_of_the_product_counters():
