@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--batch", type=int, default=4096, help="target poses per GPU per step")
     p.add_argument("--model", type=str, default=MODEL)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="bound on the approximate-IK CPU-baseline sample")
+    p.add_argument("--cpu-seconds", type=float, default=16.0, help="bound on the approximate-IK CPU-baseline sample")
     p.add_argument("--gemm-variant", type=int, default=-1)
     p.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3"],
                    help="arithmetic of the hidden contractions: exact-f32 MFMA, or the error-compensated 3x f16 MFMA split")
@@ -56,6 +56,12 @@ def parse():
     p.add_argument("--million", action="store_true",
                    help="BASELINE config 5: 1,000,000 target poses per step sharded over the ranks (batch = 1e6 / world), "
                         "one all-gather per step (strong scaling)")
+    p.add_argument("--global-batch", type=int, default=0,
+                   help="strong scaling: a FIXED global batch of this many target poses per step, split over the ranks "
+                        "(rows per rank = ceil(G / world)); e.g. --global-batch 4096 is the metric's 'batch 4096 on 1/2/4/8 GPUs' read strongly")
+    p.add_argument("--no-scaling-extras", action="store_true",
+                   help="multi-rank runs: skip the two extra measurements of the default (weak) run - strong scaling at a global batch "
+                        "of 4096 and BASELINE config 5 (1,000,000 poses per step)")
     p.add_argument("--dist-dry-run", action="store_true", help="tests only: gloo + CPU tensors + a stand-in for the engine")
     p.add_argument("--no-live-pmc", action="store_true",
                    help="do not measure roofline.traffic in this run (default at N=1: two rocprofv3 --pmc passes - FETCH_SIZE, WRITE_SIZE - "
@@ -125,6 +131,7 @@ def timed_steps(stepper, steps, warmup):
         sol = stepper.step()
     stepper.fence()
     elapsed = time.perf_counter() - t0
+    stepper.local_elapsed = elapsed  # this rank's own clock (the per-rank spread goes into the line's `rccl` object)
     if stepper.use_dist:
         import torch.distributed as dist
 
@@ -134,21 +141,112 @@ def timed_steps(stepper, steps, warmup):
     return elapsed, sol
 
 
+def rows_per_rank(mode, world, batch, global_batch):
+    """Rows one rank processes per step: weak = --batch per GPU; strong = ceil(global batch / world); million = ceil(1e6 / world)."""
+    if mode == "million":
+        return (1_000_000 + world - 1) // world
+    if mode == "strong":
+        return (global_batch + world - 1) // world
+    return batch
+
+
+def collective_proof(stepper, sol, rank, world, local_rank, dev):
+    """What makes an N>1 line self-proving: the process group's backend and size as torch.distributed reports them, the RCCL
+    version, one record per rank (device index, name, uuid / PCI bus id - N distinct GPUs), every rank's own elapsed time,
+    and a check of the LAST gathered tensor on every rank: the own shard sits bit-for-bit at the rank offset AND every other
+    rank's shard carries that rank's checksum (int64 sum of the fp32 bit patterns, exchanged in a second small collective)."""
+    import torch.distributed as dist
+
+    B = sol.shape[0]
+    full = stepper.last_gathered()
+    own = sol.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+    sums = torch.empty(world, dtype=torch.int64, device=sol.device)
+    dist.all_gather_into_tensor(sums, own)
+    ok = bool(torch.equal(full[rank * B : (rank + 1) * B], sol))
+    for r in range(world):
+        ok = ok and int(full[r * B : (r + 1) * B].contiguous().view(torch.int32).to(torch.int64).sum().item()) == int(sums[r].item())
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=sol.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    times = torch.empty(world, dtype=torch.float64, device=sol.device)
+    dist.all_gather_into_tensor(times, torch.tensor([stepper.local_elapsed], dtype=torch.float64, device=sol.device))
+    me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    if torch.device(dev).type == "cuda":
+        props = torch.cuda.get_device_properties(dev)
+        me.update(device=str(dev), name=props.name, uuid=str(getattr(props, "uuid", "")), pci_bus_id=getattr(props, "pci_bus_id", None))
+    ranks = [None] * world
+    dist.all_gather_object(ranks, me)
+    ver = None
+    try:
+        v = torch.cuda.nccl.version()
+        ver = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    t_ms = [1e3 * float(x) for x in times.tolist()]
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+            "is_rccl": dist.get_backend() == "nccl" and getattr(torch.version, "hip", None) is not None,
+            "hip": getattr(torch.version, "hip", None),
+            "collective": f"all_gather_into_tensor of [{B} x {sol.shape[1]}] f32 per rank on a side stream, once per step",
+            "gathered_shards_ok": bool(flag.item() == 1),
+            "rank_elapsed_ms_min": min(t_ms), "rank_elapsed_ms_max": max(t_ms),
+            "distinct_devices": len({(r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in ranks}),
+            "ranks": ranks}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baselines (the oracle = op-for-op the reference's PyTorch-CPU path), bounded samples
 # ---------------------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """Physical cores of this host: distinct (physical id, core id) pairs of /proc/cpuinfo, else psutil, else None."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if pairs:
+            return len(pairs)
+    except Exception:
+        pass
+    try:
+        import psutil
+
+        return psutil.cpu_count(logical=False)
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, layout, robot_name, poses_cpu, latent_cpu, budget_s):
-    """Approximate IK on this host, same batch, bounded wall time.  torch's default thread count (= all logical cores,
-    what the reference would use) is timed first; because MKL scales badly past ~32 threads on [4096x1024] GEMMs,
-    16/32/64 threads are tried too and the best rate is reported with the thread count it used."""
+    """Approximate IK on this host through the oracle (op-for-op the reference's torch-CPU path), bounded wall time.
+    SURVEY 8(d) asks for the all-physical-cores figure and the 1-thread figure: both are timed, together with torch's default
+    (= all logical cores, what the reference would run with) and 16 / 32 / 64 threads; `value` is the BEST of them with the thread
+    count that gave it.  The 1-thread pass runs on the first 512 rows of the batch (a full 4096-row pass takes ~10 s on one core).
+    Why more threads lose (profiles/r03_cpu_thread_scaling.json, tools/cpu_thread_scaling.py): one [4096 x 1024].[1024 x 1024] layer
+    is 8.6 GFLOP - 67 MFLOP (a millisecond) per thread at 128 threads - and the 12-block chain has ~390 small ops between them, so the
+    per-op fork/join of the intra-op pool across two sockets and the cross-socket reads of the 4 MB weight matrices outweigh the
+    arithmetic; the GEMM alone stops scaling at about a quarter of the cores."""
     from oracle import flow_oracle as fo
 
     n = poses_cpu.shape[0]
     default_threads = torch.get_num_threads()
-    cands = sorted({default_threads} | {t for t in (16, 32, 64) if t < default_threads})
-    per = max(1.0, budget_s / (len(cands) + 1))
+    phys = physical_cores()
+    cands = sorted({default_threads} | {t for t in (16, 32, 64) if t < default_threads} | ({phys} if phys and phys <= default_threads else set()))
+    per = max(1.0, budget_s / (len(cands) + 2))
     best = None
     notes = []
+    rates = {}
+    # 1 thread, on a 512-row slice of the same batch
+    n1 = min(512, n)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    fo.generate_ik_solutions_torch(sd, layout, robot_name, poses_cpu[:n1], latent_cpu[:n1])
+    dt1 = time.perf_counter() - t0
+    rates[1] = n1 / dt1
+    notes.append(f"1 thr: {rates[1]:.0f}/s (one pass over the first {n1} rows, {dt1:.1f} s)")
     for th in cands:
         torch.set_num_threads(th)
         t0 = time.perf_counter()
@@ -160,7 +258,9 @@ def cpu_baseline(sd, layout, robot_name, poses_cpu, latent_cpu, budget_s):
             fo.generate_ik_solutions_torch(sd, layout, robot_name, poses_cpu, latent_cpu)
         dt = time.perf_counter() - t0
         rate = n * reps / dt
-        notes.append(f"{th} thr: {rate:.0f}/s ({reps} passes, {dt:.1f} s)")
+        rates[th] = rate
+        tag = " = all physical cores" if th == phys else (" = all logical cores (torch default)" if th == default_threads else "")
+        notes.append(f"{th} thr{tag}: {rate:.0f}/s ({reps} passes, {dt:.1f} s)")
         if best is None or rate > best[0]:
             best = (rate, th)
     torch.set_num_threads(default_threads)
@@ -169,8 +269,13 @@ def cpu_baseline(sd, layout, robot_name, poses_cpu, latent_cpu, budget_s):
         "unit": "IK solutions/s",
         "cores": best[1],
         "kind": "port",
+        "one_thread": rates[1],
+        "all_physical_cores": {"cores": phys, "value": rates.get(phys)} if phys else None,
+        "all_logical_cores": {"cores": default_threads, "value": rates.get(default_threads)},
         "sample": f"passes of the same B={n} batch through oracle/flow_oracle.py (torch-CPU fp32); " + "; ".join(notes)
-                  + f"; host has {os.cpu_count()} logical cores",
+                  + f"; host has {os.cpu_count()} logical / {phys} physical cores; `value` = the best thread count. More threads lose because "
+                    "a layer is only 8.6 GFLOP and the chain has ~390 small ops: intra-op fork/join over two sockets and cross-socket "
+                    "weight reads dominate (tools/cpu_thread_scaling.py, profiles/r03_cpu_thread_scaling.json)",
     }
 
 
@@ -458,20 +563,28 @@ def main():
     if args.precision != "f32":
         solver.set_precision(args.precision)
 
-    if args.million:
-        args.batch = (1_000_000 + world - 1) // world
+    assert not (args.million and args.global_batch), "--million and --global-batch are two different strong-scaling workloads"
+    mode = "million" if args.million else ("strong" if args.global_batch else "weak")
+    args.batch = rows_per_rank(mode, world, args.batch, args.global_batch)
     B = args.batch
-    # poses = FK(q), q ~ U(lo+eps, hi-eps), numpy default_rng(seed); latents N(0,1)
-    q = torch.tensor(robot.sample_joint_angles(B, EPS_LIMITS, np.random.default_rng(rank)), device=dev)
-    poses = robot.forward_kinematics(q)
-    latent = torch.randn(B, layout.dim, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
-    eng.reserve(B)
-    stepper = ShardedStepper(lambda: solver.generate_ik_solutions(poses, latent=latent), world, rank, B, layout.ndof, dev, use_dist)
 
+    def workload(rows):
+        """SURVEY 8(d) config 2 on this rank: poses = FK(q), q ~ U(lo+eps, hi-eps), numpy default_rng(rank); latents N(0,1)."""
+        q = torch.tensor(robot.sample_joint_angles(rows, EPS_LIMITS, np.random.default_rng(rank)), device=dev)
+        p = robot.forward_kinematics(q)
+        l = torch.randn(rows, layout.dim, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+        eng.reserve(rows)
+        return p, l, ShardedStepper(lambda: solver.generate_ik_solutions(p, latent=l), world, rank, rows, layout.ndof, dev, use_dist)
+
+    poses, latent, stepper = workload(B)
     elapsed, sol = timed_steps(stepper, args.steps, args.warmup)
+    assert bool(torch.isfinite(sol).all())
+    rccl = None
     if use_dist:
         assert torch.equal(stepper.last_gathered()[rank * B : (rank + 1) * B], sol)  # own shard sits at its rank offset
-    assert bool(torch.isfinite(sol).all())
+        rccl = collective_proof(stepper, sol, rank, world, local_rank, dev)
+        assert rccl["gathered_shards_ok"], "a gathered shard does not carry its rank's checksum"
+        assert rccl["world_size"] == world
 
     # dominant kernel: per-launch HIP-event timing (on the engine's stream) of every hidden-Linear contraction inside
     # a few more, otherwise identical, steps
@@ -525,7 +638,23 @@ def main():
             "max_abs_diff_vs_f32_path": float((sol2 - sol).abs().max().item()),
             "note": "opt-in IKFlowSolver.set_precision('f16x3'): a = hi + lo/2048 operand split, 3 v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate",
         }
-    if world == 1 and rank == 0 and not args.no_cells and not args.million:
+    if use_dist and mode == "weak" and not args.no_scaling_extras and not TEST_BACKEND:
+        # the two strong-scaling readings of the metric, measured in the same launch (all ranks take part): a FIXED global batch of
+        # 4096 poses per step split over the ranks (512 rows per rank at N = 8: the small-batch kernels), and BASELINE config 5
+        # (1,000,000 poses per step, 1e6 / N per rank in 16384-row chunks); each with the one all-gather per step
+        extra["scaling_modes"] = {}
+        for name, m2, g2, st, wu in (("strong_global_batch_4096", "strong", 4096, max(20, args.steps), 5), ("million_poses_config5", "million", 0, 3, 1)):
+            rows = rows_per_rank(m2, world, 0, g2)
+            _, _, st2 = workload(rows)
+            dt, s2 = timed_steps(st2, st, wu)
+            proof = collective_proof(st2, s2, rank, world, local_rank, dev)
+            extra["scaling_modes"][name] = {"value": world * rows * st / dt, "unit": "IK solutions/s", "ms_per_step": 1e3 * dt / st, "steps": st,
+                                            "warmup": wu, "rows_per_rank": rows, "global_batch": world * rows, "scaling": "strong",
+                                            "gathered_shards_ok": proof["gathered_shards_ok"],
+                                            "rank_elapsed_ms_min": proof["rank_elapsed_ms_min"], "rank_elapsed_ms_max": proof["rank_elapsed_ms_max"]}
+            del st2
+        eng.reserve(B)
+    if world == 1 and rank == 0 and not args.no_cells and not args.million and not args.global_batch:
         extra["cells"] = run_cells(solver, eng, robot, layout, dev, args.precision)
         extra["cells_note"] = ("the cells of BASELINE.json's metric other than the headline (same engine, same weights, one MI355X, "
                                "inputs resident, wall clock around synchronised calls); exact-IK LM steps are evaluated in fp64 "
@@ -541,13 +670,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if args.million else "weak",
+        "scaling": "weak" if mode == "weak" else "strong",
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "f32" else "f16x3 (error-compensated f16 MFMA, f32 accumulate)",
         "data": "synthetic (seeded random weights of the released architecture; poses = FK(uniform q); N(0,1) latents)",
         "config": {"workload": f"{args.model} generate_ik_solutions, B={B} poses per GPU per step, clamp_to_joint_limits"
-                               + (" (1,000,000 poses per step over all ranks)" if args.million else ""),
-                   "global_batch": world * B, "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
+                               + (" (1,000,000 poses per step over all ranks)" if args.million else "")
+                               + (f" (fixed global batch of {args.global_batch} poses per step split over the ranks)" if mode == "strong" else ""),
+                   "global_batch": world * B, "scaling_mode": mode,
+                   "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": live_traffic if live_traffic is not None else traffic,
                      "traffic_unit": "HBM bytes per launch",
@@ -560,10 +691,19 @@ def main():
                      "rocprof_avg_launch_us": prof_us, "rocprof_source": prof_src,
                      "frac_rocprof": (flop_per_launch / (prof_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if prof_us else None},
         "extra": extra,
-        "multi_gpu": (f"{world} ranks measured in this run" if world > 1 else
-                      "N=1 run; the N>1 path (row shards, one all_gather_into_tensor per step on a side stream) is covered by "
-                      "gloo world-2 tests on CPU; no multi-GPU curve has been measured by the builder (8-GPU runs are the driver's)"),
+        "multi_gpu": ((f"{world} ranks measured in this run (see `rccl`: backend, world size, per-rank devices and times, gathered-shard "
+                       "check). " if world > 1 else
+                       "N=1 run; the N>1 path (row shards, one all_gather_into_tensor per step on a side stream) runs under RCCL at world "
+                       "size 1 in the GPU tests and under gloo at world size 2 on CPU; no multi-GPU curve has been measured by the builder "
+                       "(8-GPU runs are the driver's). ")
+                      + "The north star's '>= 6x at 8 GPUs' is judged on WEAK scaling - this line's `value` across N = 1/2/4/8 at 4096 "
+                        "poses per GPU per step - and on BASELINE config 5 (`--million`, or extra.scaling_modes.million_poses_config5 of a "
+                        "multi-rank run: 1,000,000 poses per step, 125,000 per GPU at N = 8). A fixed global batch of 4096 "
+                        "(`--global-batch 4096`, extra.scaling_modes.strong_global_batch_4096) leaves 512 rows per GPU at N = 8 - the "
+                        "launch-latency-bound small-batch regime - and is reported beside them, not as the target."),
     }
+    if rccl is not None:
+        out["rccl"] = rccl
     if TEST_BACKEND:
         out["test_backend"] = f"{TEST_BACKEND}: all {world} ranks share cuda:0 - a test of the N>1 code path, NOT a measurement"
         out["metric"] = "TEST RUN (ranks share one GPU): no throughput claim"
@@ -588,7 +728,8 @@ def dry_run(args, world, rank, use_dist):
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    B = (1_000_000 + world - 1) // world if args.million else args.batch
+    mode = "million" if args.million else ("strong" if args.global_batch else "weak")
+    B = rows_per_rank(mode, world, args.batch, args.global_batch)
     g = torch.Generator().manual_seed(rank)
     poses = torch.randn(B, 7, generator=g)
     latent = torch.randn(B, 7, generator=g)
@@ -606,11 +747,12 @@ def dry_run(args, world, rank, use_dist):
         flag = torch.tensor([1.0 if ok else 0.0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = bool(flag.item() == 1.0)
+    proof = collective_proof(stepper, sol, rank, world, int(os.environ.get("LOCAL_RANK", "0")), "cpu") if use_dist else None
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": "DRY RUN (gloo, CPU tensors, stand-in compute): no throughput claim", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathered_ok": ok,
-                          "scaling": "strong" if args.million else "weak", "global_batch": world * B,
-                          "ms_per_step": 1000.0 * elapsed / max(args.steps, 1)}), flush=True)
+                          "scaling": "weak" if mode == "weak" else "strong", "global_batch": world * B, "rows_per_rank": B,
+                          "ms_per_step": 1000.0 * elapsed / max(args.steps, 1), "rccl": proof}), flush=True)
     if use_dist:
         dist.destroy_process_group()
     if not ok:

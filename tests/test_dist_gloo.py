@@ -72,7 +72,7 @@ def test_sharded_rows_gloo(world, n):
 
 # ---- bench.py's own multi-rank plumbing (env handling, process group, ShardedStepper step / fence / gather, max over
 # ranks, the one JSON line) under gloo on CPU tensors, launched exactly as the driver launches it ------------------------
-@pytest.mark.parametrize("extra", [[], ["--million"]])
+@pytest.mark.parametrize("extra", [[], ["--million"], ["--global-batch", "4097"]])
 def test_bench_dry_run_under_torch_distributed_run(extra):
     import json
     import subprocess
@@ -89,7 +89,11 @@ def test_bench_dry_run_under_torch_distributed_run(extra):
     out = json.loads(lines[0])
     assert out["dry_run"] is True and out["value"] is None and out["n_gpus"] == 2 and out["gathered_ok"] is True
     assert out["scaling"] == ("strong" if extra else "weak")
-    assert out["global_batch"] == (1_000_000 if extra else 514)
+    assert out["global_batch"] == (1_000_000 if extra == ["--million"] else 4098 if extra else 514)  # ceil(4097 / 2) rows per rank
+    rc = out["rccl"]  # the self-proof every multi-rank line carries (here: gloo, two CPU processes)
+    assert rc["backend"] == "gloo" and rc["world_size"] == 2 and rc["gathered_shards_ok"] is True and not rc["is_rccl"]
+    assert [r["rank"] for r in rc["ranks"]] == [0, 1] and len({r["pid"] for r in rc["ranks"]}) == 2
+    assert 0 < rc["rank_elapsed_ms_min"] <= rc["rank_elapsed_ms_max"]
 
 
 class _FakeSolver:
@@ -146,8 +150,9 @@ def test_sharded_solver_entry_points_gloo(world, n):
     assert all(ok for _, ok in res), res
 
 
-def _worker_real_solver(rank, world, port, n, q):
-    """Both ranks on cuda:0 of the one-GPU box, gloo in place of RCCL: the real IKFlowSolver behind the sharded entry points."""
+def _worker_real_solver(rank, world, port, n, q, backend="gloo"):
+    """Both ranks on cuda:0 of the one-GPU box, gloo in place of RCCL: the real IKFlowSolver behind the sharded entry points.
+    With backend="nccl" (world size 1 on a one-GPU box) the same calls run through RCCL itself."""
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -157,8 +162,14 @@ def _worker_real_solver(rank, world, port, n, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
+        assert dist.get_backend() == backend and dist.get_world_size() == world
         dev = "cuda:0"
         robot, hp, lay, sd = tiny_model(seed=4)
         s = IKFlowSolver(hp, robot)
@@ -203,3 +214,55 @@ def test_sharded_entry_points_with_the_real_solver_two_ranks_one_gpu():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(all(ok) for _, ok in res), res
+
+
+@pytest.mark.gpu
+def test_sharded_entry_points_through_rccl_world_size_one():
+    """ikflow_amd/dist.py under the backend the 8-GPU node will use: init_process_group("nccl", device_id=...) = RCCL, world size 1 (what a
+    one-GPU box allows): the padded all_gather_into_tensor of the approximate path (given latents and drawn latents), the packed
+    solutions + valid-flag gather of the exact path, destroy_process_group.  n is odd so the padding branch is taken."""
+    world, n = 1, 1501
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_real_solver, args=(0, world, _free_port(), n, q, "nccl"))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert all(res[1]), res
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [[], ["--global-batch", "4096"], ["--million"]])
+def test_bench_under_torch_distributed_run_with_rccl_world_size_one(mode):
+    """bench.py launched exactly as the driver launches it for N > 1 - `python -m torch.distributed.run ... bench.py --gpus N` - with the
+    real engine and the real backend (nccl = RCCL), at the world size a one-GPU box allows: RCCL init with device_id, the all-gather on its
+    side stream behind an event, record_stream, fence + barrier, the max-over-ranks all_reduce, the `rccl` proof object, destroy."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("IKF_BENCH_TEST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+           "--no-cells", "--no-split-extra", "--no-cpu-baseline", "--no-live-pmc"] + mode
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    rc = out["rccl"]
+    assert rc["backend"] == "nccl" and rc["is_rccl"] and rc["world_size"] == 1 and rc["gathered_shards_ok"] is True
+    assert rc["distinct_devices"] == 1 and len(rc["ranks"]) == 1 and rc["ranks"][0]["rank"] == 0 and rc["rccl_version"]
+    assert rc["rank_elapsed_ms_min"] <= rc["rank_elapsed_ms_max"] and "test_backend" not in out
+    want_rows = 1_000_000 if mode == ["--million"] else 4096
+    assert out["n_gpus"] == 1 and out["config"]["global_batch"] == want_rows and out["value"] > 0
+    assert out["scaling"] == ("strong" if mode else "weak") and out["config"]["scaling_mode"] == ("million" if mode == ["--million"] else "strong" if mode else "weak")
+    assert abs(out["value"] - want_rows * 4 / (out["ms_per_step"] * 4e-3)) <= 1e-6 * out["value"]
+    if not mode:  # the default multi-rank run also measures both strong-scaling readings in the same launch
+        sm = out["extra"]["scaling_modes"]
+        assert sm["strong_global_batch_4096"]["global_batch"] == 4096 and sm["strong_global_batch_4096"]["gathered_shards_ok"]
+        assert sm["million_poses_config5"]["global_batch"] == 1_000_000 and sm["million_poses_config5"]["gathered_shards_ok"]
+        assert sm["million_poses_config5"]["value"] > 5e5

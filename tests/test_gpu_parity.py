@@ -225,6 +225,34 @@ def test_full_batch_properties_4096():
     assert bool(((full >= lo_t) & (full <= hi_t)).all())
 
 
+@pytest.mark.parametrize("which,n", [("panda", 4096), ("fetch_arm", 8192)])
+def test_every_row_of_the_baseline_batches_against_the_oracle(which, n):
+    """BASELINE configs 2 and 4 (and the round-0 flow seeds of config 3: the same 4096 Panda rows through the same kernels) with
+    EVERY row compared against the torch-CPU oracle - all 32 (64) row tiles of the headline launch, i.e. every workgroup on
+    every XCD, not a slice - in both precisions, clamped (the API default, what bench.py runs) and unclamped (f32).
+    Tolerance 1e-5 (north star), reported per 128-row tile."""
+    robot, hp, lay, sd = (panda_model if which == "panda" else fetch_arm_model)()
+    s = _solver(robot, hp, sd)
+    _, poses = reachable_poses(robot, n, 0 if which == "panda" else 40)
+    lat = latents(n, lay.dim, 1 if which == "panda" else 41)
+    P, L = poses.to(DEV), lat.to(DEV)
+    ref = {c: fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=c) for c in (True, False)}
+    assert ref[True].shape == (n, robot.ndof)
+    worst = {}
+    for prec, clamps in (("f32", (True, False)), ("f16x3", (True,))):
+        s.set_precision(prec)
+        assert s.engine(DEV).precision == prec
+        for c in clamps:
+            got = s.generate_ik_solutions(P, latent=L, clamp_to_joint_limits=c).cpu()
+            err = (got - ref[c]).abs().max(1).values  # per row
+            tiles = err.reshape(n // 128, 128).max(1).values  # per 128-row tile of the contraction launch
+            worst[(prec, c)] = (err.max().item(), int(tiles.argmax()))
+            assert bool(torch.isfinite(got).all())
+            assert (tiles <= FLOW_TOL).all(), f"{which} {prec} clamp={c}: tile {int(tiles.argmax())} is {tiles.max().item():.2e} from the oracle"
+    print(f"{which} B={n}: max |hip - oracle| over ALL rows: " + ", ".join(f"{k[0]}{'' if k[1] else ' unclamped'} {v[0]:.2e} (tile {v[1]})" for k, v in worst.items()))
+    assert s.engine(DEV).split_fallback_count == 0
+
+
 def test_chunked_large_batch_equals_small_batches():
     robot, hp, lay, sd = tiny_model()
     s = _solver(robot, hp, sd)
@@ -928,6 +956,9 @@ def _random_flow_configs(count, seed):
     return out
 
 
+_FUZZ_STATS = {"runs": 0, "noise_branch": []}
+
+
 @pytest.mark.parametrize("cfg", _random_flow_configs(int(os.environ.get("IKF_FUZZ_COUNT", "32")), int(os.environ.get("IKF_FUZZ_SEED", "20260928"))), ids=lambda c: "-".join(str(v) for v in c.values()))
 def test_flow_random_configurations(cfg):
     """Seeded random draws over everything IkflowModelParameters / glow_cNF_model (ikflow/model.py:17-41,300-354) can express within
@@ -957,6 +988,21 @@ def test_flow_random_configurations(cfg):
         err = ((got - ref).abs() / scale).max().item()
         err64 = ((got - ref64).abs() / scale).max().item()
         assert err <= FLOW_TOL or err64 <= 4 * cpu_noise, f"{cfg} {prec} n={n}: {err:.2e} vs fp32, {err64:.2e} vs fp64 (cpu {cpu_noise:.2e})"
+        _FUZZ_STATS["runs"] += 1
+        if err > FLOW_TOL:  # passed on the ill-conditioned-case branch only: counted, and bounded by the test below
+            _FUZZ_STATS["noise_branch"].append(f"{'-'.join(str(v) for v in cfg.values())} {prec} n={n}: {err:.2e} vs fp32 cpu, {err64:.2e} vs fp64, cpu noise {cpu_noise:.2e}")
+
+
+def test_flow_random_configurations_share_of_ill_conditioned_cases():
+    """The fuzz cases above may pass on `err64 <= 4 * cpu_noise` when the fp32 CPU path itself is further than 1e-5 from fp64 (gain-2.5
+    random weights).  That branch must stay the exception: report every case that took it, fail above 10 % of the runs."""
+    runs, noisy = _FUZZ_STATS["runs"], _FUZZ_STATS["noise_branch"]
+    print(f"fuzz: {len(noisy)} of {runs} (configuration, precision) runs left the 1e-5 contract against the fp32 CPU path and passed on the fp64 bound")
+    for line in noisy:
+        print("   ", line)
+    if runs == 0:
+        pytest.skip("the fuzz cases did not run in this session")
+    assert len(noisy) <= 0.10 * runs, noisy
 
 
 @pytest.mark.parametrize("n_hidden", [1, 2, 3])
