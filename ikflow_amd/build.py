@@ -43,7 +43,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = os.environ.get("IKF_HIPCC_FLAGS_" + src.split(".")[0].upper(), "").split()  # probes: flags for ONE unit, e.g. IKF_HIPCC_FLAGS_FLOW_FUSED=-DIKF_TRACE
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -28,6 +28,10 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #ifdef IKF_TRACE
 __device__ unsigned long long* ikf_trace_buf = nullptr;
 #define IKF_TSTAMP(i) if (threadIdx.x == 0 && ikf_trace_buf) ikf_trace_buf[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+}  // namespace ikf
+// probe builds of the LIBRARY only (IKF_HIPCC_FLAGS=-DIKF_TRACE python -m ikflow_amd.build): point the stamp buffer at caller memory
+extern "C" int ikf_debug_set_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &buf, sizeof(buf)); }
+namespace ikf {
 #else
 #define IKF_TSTAMP(i)
 #endif
@@ -71,7 +75,15 @@ struct PendingLoads {
   float xv[ITEMS], bias[ITEMS], a[ITEMS][32];
 };
 
-template <int NT, int R>
+// SC1: the partial sums were published inside THIS launch by other workgroups (TailSync): agent-scope loads, which bypass
+// this CU's L1 (it may hold the lines of an earlier subnet: the buffer is reused).
+template <bool SC1>
+__device__ __forceinline__ float load_partial(const float* p) {
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+template <int NT, int R, bool SC1 = false>
 __device__ __forceinline__ void pending_issue_loads(const PendingCoupling& pc, const float* __restrict__ x_src, int D, int L1,
                                                     int m0, int M, int t, PendingLoads<(R * ROWBUF + NT - 1) / NT>& pl) {
   constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
@@ -86,7 +98,7 @@ __device__ __forceinline__ void pending_issue_loads(const PendingCoupling& pc, c
     const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + d;  // P rows are padded to the tile: no clamp needed
     pl.bias[it] = has_sum ? pc.b_last[d] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) pl.a[it][q] = (has_sum && q < pc.slots) ? p[(size_t)q * pc.slot_stride] : 0.f;
+    for (int q = 0; q < 32; ++q) pl.a[it][q] = (has_sum && q < pc.slots) ? load_partial<SC1>(p + (size_t)q * pc.slot_stride) : 0.f;
   }
 }
 
@@ -189,6 +201,8 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
       pose_v[it] = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
     }
   }
+  if (e.zero_words != nullptr && blockIdx.x == 0 && blockIdx.y == 0)  // the call's arrival counters (TailSync), visible to the
+    for (int i = t; i < e.n_zero; i += NT) e.zero_words[i] = 0u;     // later launches through the kernel boundary
   IKF_TSTAMP(0)
   finish_pending_rows<NT, ER>(e.pend, pl, D, e.L1, e.clamp, m0, cat, U, t);
   IKF_TSTAMP(1)
@@ -261,10 +275,156 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// hidden contraction; EPI_RED: reduce the last Linear in the epilogue instead of storing the activation
+// The next subnet's entry phase in the tail of the launch that produced its pending coupling (TailSync, ikf_internal.h).
+// Called by every thread of a workgroup that has just stored its partial-sum slots of rows [m0, m0 + R) WRITE-THROUGH
+// (16-byte sc1 stores).  Protocol (placement-independent; cdna_hip_programming.md, Guideline 16, form R1 with an arrival
+// counter as the flag): every storing wave drains its stores, barrier, one lane adds 1 to the row tile's agent-scope
+// counter; one wave polls the counter (relaxed agent-scope loads, s_sleep between polls, bounded); barrier; the slots of
+// ALL column tiles are read with agent-scope loads.  Then exactly k_subnet_entry's arithmetic: the pending coupling of the R
+// rows (every sibling repeats it - 2 * R * 16 sums), the new state published by the first column tile, and this workgroup's
+// BNW columns of the first Linear + LeakyReLU -> h_out.  `smem`: 3 * R * ROWBUF + 17 * BNW floats, free for reuse.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool EPI_RED, int CFG>
-__global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) void k_flow_gemm(FusedGemmArgs g) {
+constexpr unsigned kTailSpinLimit = 1u << 21;  // x (s_sleep 8 + one load) ~ a second: only reached when a sibling never runs
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store16_wt(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off, floatx4 v) {  // write-through
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), rs, byte_off, 0, /*aux: sc1*/ 16);
+}
+
+template <int NT, int R, int BNW>
+__device__ __forceinline__ void tail_next_entry(const EntryArgs& e, const TailSync& ts, float* smem, int tm, int m0, int n0,
+                                                bool first_col_tile, int t) {
+  constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
+  constexpr int C4 = BNW / 4;                  // float4 column groups of this workgroup's slice
+  constexpr int WF4 = (ROWBUF + 1) * C4;       // float4 of the staged first-Linear slice: 16 input rows (zero beyond n_in) + bias
+  constexpr int WPT = (WF4 + NT - 1) / NT;
+  float* cat = smem;
+  float* sums = cat + R * ROWBUF;
+  float* U = sums + R * ROWBUF;
+  float* Wl = U + R * ROWBUF;                  // [ROWBUF + 1][BNW]
+  const int M = e.M, D = e.D, n_in = ts.n_in;
+
+  // ---- publish: this workgroup's slots are on their way; once every wave's stores have left, one lane arrives
+  IKF_TSTAMP(43)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // (also: every wave is done with the epilogue's LDS tiles)
+  if (t == 0) __hip_atomic_fetch_add(ts.arrive + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  IKF_TSTAMP(44)
+
+  // ---- everything that does not depend on the siblings is requested before the wait: the first-Linear slice (cold: it is
+  // the NEXT subnet's weight), the pose entries and (inside pending_issue_loads, below) the state rows
+  floatx4 wst[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int idx = t + i * NT, k = idx / C4, c4 = idx - k * C4;
+    floatx4 v = {0.f, 0.f, 0.f, 0.f};
+    if (idx < WF4) {
+      if (k < n_in) v = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width + n0)[c4];
+      else if (k == ROWBUF) {
+        v = reinterpret_cast<const floatx4*>(e.b1 + n0)[c4];
+        if (e.ps.softflow != 0.0f) v += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft + n0)[c4];
+      }
+    }
+    wst[i] = v;
+  }
+  float pose_v[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = t + it * NT, ur = idx / ROWBUF, uk = idx % ROWBUF;
+    pose_v[it] = 0.f;
+    if (idx < R * ROWBUF && uk >= e.n_x && uk < n_in) {
+      int gr = m0 + ur;
+      gr = gr < M ? gr : M - 1;
+      const long long grow = e.row0 + gr;
+      const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
+      const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
+      pose_v[it] = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
+    }
+  }
+
+  // ---- wait for the row tile's other column tiles: ONE wave polls ONE word
+  IKF_TSTAMP(45)
+  if (t < 64) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ts.arrive + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ts.target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > kTailSpinLimit) {  // a sibling is not resident (the launcher sizes the grid so that this cannot happen)
+        if (t == 0) __hip_atomic_store(ts.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < WPT; ++i)
+    if (t + i * NT < WF4) reinterpret_cast<floatx4*>(Wl)[t + i * NT] = wst[i];
+  __syncthreads();
+  IKF_TSTAMP(46)
+
+  // ---- the pending coupling of the R rows, from every column tile's slots
+  PendingLoads<ITEMS> pl;
+  pending_issue_loads<NT, R, true>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);
+  finish_pending_rows<NT, R>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
+  IKF_TSTAMP(47)
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = t + it * NT, ur = idx / ROWBUF, uk = idx % ROWBUF;
+    if (idx >= R * ROWBUF) continue;
+    if (first_col_tile && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
+    U[ur * ROWBUF + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v[it];
+  }
+  __syncthreads();
+  IKF_TSTAMP(48)
+
+  // ---- first Linear + LeakyReLU: C4 column groups x (NT / C4) row groups
+  constexpr int RG = NT / C4, RPT = (R + RG - 1) / RG;
+  const int tc = t % C4, rg = t / C4;
+  if (rg * RPT < R) {
+    floatx4 w[ROWBUF];
+#pragma unroll
+    for (int k = 0; k < ROWBUF; ++k) w[k] = reinterpret_cast<const floatx4*>(Wl + k * BNW)[tc];
+    const floatx4 b = reinterpret_cast<const floatx4*>(Wl + ROWBUF * BNW)[tc];
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(e.h_out, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 4
+    for (int r = rg * RPT; r < rg * RPT + RPT && r < R; ++r) {
+      float u[ROWBUF];
+#pragma unroll
+      for (int q = 0; q < ROWBUF / 4; ++q) {
+        const floatx4 uq = *reinterpret_cast<const floatx4*>(U + r * ROWBUF + q * 4);
+        u[q * 4 + 0] = uq.x; u[q * 4 + 1] = uq.y; u[q * 4 + 2] = uq.z; u[q * 4 + 3] = uq.w;
+      }
+      floatx4 acc = b;
+#pragma unroll
+      for (int k = 0; k < ROWBUF; ++k)
+        if (k < n_in) acc += u[k] * w[k];  // the entry kernel's chain: bias, then k ascending
+      acc.x = acc.x > 0.f ? acc.x : acc.x * e.slope;
+      acc.y = acc.y > 0.f ? acc.y : acc.y * e.slope;
+      acc.z = acc.z > 0.f ? acc.z : acc.z * e.slope;
+      acc.w = acc.w > 0.f ? acc.w : acc.w * e.slope;
+      // h rows are padded to a multiple of 128: unpredicated; write-through, so that nothing is left to flush at the launch's end
+      store16_wt(rsH, (unsigned)(((size_t)(m0 + r) * e.width + n0 + tc * 4) * 4), acc);
+    }
+  }
+  IKF_TSTAMP(49)
+#ifdef IKF_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IKF_TSTAMP(50)
+#endif
+}
+constexpr size_t tail_lds_floats(int R, int BNW) { return (size_t)3 * R * ROWBUF + (size_t)(ROWBUF + 1) * BNW; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// hidden contraction; EPI_RED: reduce the last Linear in the epilogue instead of storing the activation;
+// FUSE (with EPI_RED): the next subnet's entry phase runs in the tail (tail_next_entry)
+// ---------------------------------------------------------------------------------------------------------------
+struct NoTail {};
+struct FuseTail {
+  EntryArgs e;
+  TailSync ts;
+};
+template <bool EPI_RED, int CFG, bool FUSE = false>
+__global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) void k_flow_gemm(
+    FusedGemmArgs g, std::conditional_t<FUSE, FuseTail, NoTail> ft) {
+  static_assert(!FUSE || EPI_RED, "the fused tail follows the partial-sum epilogue");
   using TC = TileCfg<CFG>;
   constexpr int BM = TC::BM, BN = TC::BN, BK = FBK, FWAVES_M = TC::WAVES_M, FWAVES_N = TC::WAVES_N;
   constexpr int NT = FWAVES_M * FWAVES_N * 64;
@@ -490,7 +650,13 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
           const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + row_h;
           float v = acc[i][j][r] + bv;
           v = v > 0.f ? v : v * g.slope;
+#if defined(IKF_EPI_NOSTORE)   // probes only (tools/gemm_probe.hip): what the activation stores + the flush behind them cost
+          if (v == 123456.789f) g.C[(size_t)row * N + col] = v;
+#elif defined(IKF_EPI_SC1)     // probes only: write-through (agent-scope) stores instead of write-back ones
+          __hip_atomic_store(&g.C[(size_t)row * N + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
           g.C[(size_t)row * N + col] = v;
+#endif
         }
       }
     }
@@ -542,13 +708,23 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
         pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
       }
-      // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7
-      float* pout = g.P_out + (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int o = (r & 3) + 8 * (r >> 2) + row_h;
-        pout[o] = pacc[r];
+      // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7:
+      // registers 0..3 are outputs row_h .. row_h+3, registers 4..7 outputs 8+row_h .. 8+row_h+3 - two 16-byte stores
+      const size_t pidx = (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE + row_h;
+      const floatx4 p_lo = {pacc[0], pacc[1], pacc[2], pacc[3]}, p_hi = {pacc[4], pacc[5], pacc[6], pacc[7]};
+      if constexpr (FUSE) {
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(g.P_out, 0, 0x7fffffff, 0x00020000);
+        store16_wt(rsP, (unsigned)(pidx * 4), p_lo);
+        store16_wt(rsP, (unsigned)((pidx + 8) * 4), p_hi);
+      } else {
+        *reinterpret_cast<floatx4*>(g.P_out + pidx) = p_lo;
+        *reinterpret_cast<floatx4*>(g.P_out + pidx + 8) = p_hi;
       }
+    }
+    if constexpr (FUSE) {
+      static_assert(3 * STAGE >= (int)tail_lds_floats(BM, BN), "the tail's LDS fits in the stage area");
+      IKF_TSTAMP(42)
+      tail_next_entry<NT, BM, BN>(ft.e, ft.ts, smem, tm, m0, n0, tn == 0, t);
     }
   }
   IKF_TSTAMP(41)
@@ -613,7 +789,7 @@ constexpr size_t skinny_lds() {
 // tail of the small-batch kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.
 // Call after a barrier that ends every fragment read of the loop (smem is reused from its start).
 // ---------------------------------------------------------------------------------------------------------------
-template <bool EPI_RED, int NH>
+template <bool EPI_RED, int NH, bool FUSE = false>
 __device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx16& acc, float* smem, int m0, int n0, int t,
                                             int lane, int wave, int nh, int kq) {
   constexpr int BM = KBM, BN = NH * 32, NT = NH * KKS * 64, KS = KKS;
@@ -689,22 +865,33 @@ __device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx
     }
     __syncthreads();
     if (wave == 0) {
-      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE;
+      float fin8[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         float v = pacc[r];
 #pragma unroll
         for (int w = 1; w < NQW; ++w) v += part[(w * 8 + r) * 64 + lane];
-        const int o = (r & 3) + 8 * (r >> 2) + row_h;
-        pout[o] = v;
+        fin8[r] = v;
+      }
+      // registers 0..3 are outputs row_h .. row_h+3, registers 4..7 outputs 8+row_h .. : two 16-byte stores per lane
+      const size_t pidx = (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + (lane & 31)) * IKF_PSTRIDE + row_h;
+      const floatx4 p_lo = {fin8[0], fin8[1], fin8[2], fin8[3]}, p_hi = {fin8[4], fin8[5], fin8[6], fin8[7]};
+      if constexpr (FUSE) {  // published inside the launch (TailSync): write-through
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(g.P_out, 0, 0x7fffffff, 0x00020000);
+        store16_wt(rsP, (unsigned)(pidx * 4), p_lo);
+        store16_wt(rsP, (unsigned)((pidx + 8) * 4), p_hi);
+      } else {
+        *reinterpret_cast<floatx4*>(g.P_out + pidx) = p_lo;
+        *reinterpret_cast<floatx4*>(g.P_out + pidx + 8) = p_hi;
       }
     }
   }
   IKF_TSTAMP(41)
 }
 
-template <bool EPI_RED, int NH>
-__global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArgs g) {
+template <bool EPI_RED, int NH, bool FUSE = false>
+__global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArgs g, std::conditional_t<FUSE, FuseTail, NoTail> ft) {
+  static_assert(!FUSE || EPI_RED, "the fused tail follows the partial-sum epilogue");
   constexpr int BM = KBM, BN = NH * 32, BK = KBK, NT = NH * KKS * 64, KS = KKS;
   constexpr int LDK = BK + 4;
   constexpr int KQ4 = BK / 4;           // float4 per tile row
@@ -831,7 +1018,11 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
 #undef IKK_LDA
 #undef IKK_LDW
   __syncthreads();  // all fragment reads done before the stage area is reused
-  skinny_tail<EPI_RED, NH>(g, acc, smem, m0, n0, t, lane, wave, nh, kq);
+  skinny_tail<EPI_RED, NH, FUSE>(g, acc, smem, m0, n0, t, lane, wave, nh, kq);
+  if constexpr (FUSE) {
+    static_assert(skinny_lds<NH>() >= sizeof(float) * tail_lds_floats(BM, BN), "the tail's LDS fits");
+    tail_next_entry<NT, BM, BN>(ft.e, ft.ts, smem, tm, m0, n0, tn == 0, t);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1035,11 +1226,21 @@ hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream
 template <bool EPI_RED, int NH>
 static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = skinny_lds<NH>();
-  auto kern = k_flow_gemm_skinny<EPI_RED, NH>;
+  auto kern = k_flow_gemm_skinny<EPI_RED, NH, false>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a, NoTail{});
+  return hipGetLastError();
+}
+static hipError_t launch_skinny_tail(const FusedGemmArgs& a, const FuseTail& ft, hipStream_t s) {
+  constexpr int NH = 2;
+  constexpr size_t smem = skinny_lds<NH>();
+  auto kern = k_flow_gemm_skinny<true, NH, true>;
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
+  const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a, ft);
   return hipGetLastError();
 }
 
@@ -1113,13 +1314,45 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
   using TC = TileCfg<CFG>;
   constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
   constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (FBK + 4) * sizeof(float);
-  auto kern = k_flow_gemm<EPI_RED, CFG>;
+  auto kern = k_flow_gemm<EPI_RED, CFG, false>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long tiles_m = ((long long)a.M + TC::BM - 1) / TC::BM;
   const long long grid = tiles_m * (a.N / TC::BN);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a, NoTail{});
   return hipGetLastError();
+}
+static hipError_t launch_fg_tail(const FusedGemmArgs& a, const FuseTail& ft, hipStream_t s) {
+  using TC = TileCfg<0>;
+  constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
+  constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (FBK + 4) * sizeof(float);
+  auto kern = k_flow_gemm<true, 0, true>;
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
+  const long long grid = (((long long)a.M + TC::BM - 1) / TC::BM) * (a.N / TC::BN);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a, ft);
+  return hipGetLastError();
+}
+
+// The in-launch hand-over needs every workgroup of the launch resident at once (a workgroup waits for its row tile's other
+// column tiles): both kernels that carry it run one workgroup per CU (LDS), so the grid may have at most 256 tiles.
+constexpr int kResidentTiles = 256;
+int fused_tail_col_tiles(int cfg, int width) { return cfg == 0 ? width / TileCfg<0>::BN : width / KBN; }
+bool fused_tail_ok(int cfg, long long rows, int width, int D, int n_out) {
+  if (cfg != 0 && cfg != kSkinnyCfg) return false;
+  const int bm = cfg == 0 ? TileCfg<0>::BM : KBM, bn = cfg == 0 ? TileCfg<0>::BN : KBN;
+  if (width % bn != 0 || width / 64 > 32) return false;  // (the sc1 slot loads cover the first 32 slots)
+  if (cfg == kSkinnyCfg && width % (2 * KBK) != 0) return false;
+  const long long tiles = ((rows + bm - 1) / bm) * (width / bn);
+  return tiles <= kResidentTiles && D <= ROWBUF && n_out <= ROWBUF;
+}
+hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArgs& e, const TailSync& ts, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (!fused_tail_ok(cfg, a.M, a.N, e.D, e.pend.n_out) || a.K != a.N || a.n_out > 16 || ts.n_in > ROWBUF - 1 || e.width != a.N ||
+      e.split_out || ts.arrive == nullptr || ts.give_up == nullptr || (cfg == kSkinnyCfg && a.Wf == nullptr) || a.K % 64 != 0 || a.K < 128)
+    return hipErrorInvalidValue;
+  FuseTail ft{e, ts};
+  return cfg == 0 ? launch_fg_tail(a, ft, s) : launch_skinny_tail(a, ft, s);
 }
 
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {

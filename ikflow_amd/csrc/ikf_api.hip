@@ -59,6 +59,12 @@ struct ikf_model {
   int gemm_variant = -1;  // -1 = choose by batch size
   int tile_cfg = -1;      // fused pipeline: -1 = choose by batch size, 0..3 forced (variant 100..103)
   int fuse_entry = 1;     // small batches: entry kernel + first hidden contraction as one launch (0: always two launches)
+  // the next subnet's entry phase in the tail of the last hidden contraction (TailSync).  OFF by default: measured slower than the
+  // k_subnet_entry launch it replaces (r03: +3.6 % per call at 4096 rows, +7.4 % at 512) - kept as a tested,
+  // bit-identical opt-in (ikf_set_gemm_variant 121) because it is the priced answer to "hand over inside the launch"
+  int fuse_tail = 0;
+  unsigned* d_arrive = nullptr;  // [kArriveWords] row-tile arrival counters of the fused tail (zeroed by every call's first entry kernel)
+  int* h_give_up = nullptr;      // pinned, device-visible: set by a workgroup whose in-launch wait ran out
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
   uint16_t* split_arena = nullptr;  // split-32 images of the hidden Linear weights
   std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
@@ -107,6 +113,7 @@ struct ikf_model {
   double last_event_overhead_ms = 0.0;
 };
 
+static const int kArriveWords = 256;  // >= row tiles of any launch that hands over inside the launch (<= 256 tiles)
 static const size_t kProfMaxPairs = 8192;
 static hipError_t prof_mark(ikf_model* m, hipStream_t s) {
   if (!m->prof_on || m->prof_used >= 2 * kProfMaxPairs) return hipSuccess;
@@ -244,6 +251,10 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   if (e == hipSuccess) e = hipMalloc(&m->d_split_flag, sizeof(int));
   if (e == hipSuccess) e = hipMemset(m->d_split_flag, 0, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&m->h_split_flag, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&m->d_arrive, sizeof(unsigned) * kArriveWords);
+  if (e == hipSuccess) e = hipMemset(m->d_arrive, 0, sizeof(unsigned) * kArriveWords);
+  if (e == hipSuccess) e = hipHostMalloc(&m->h_give_up, sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) *m->h_give_up = 0;
   if (e != hipSuccess) {
     ikf_destroy(m);
     return fail(IKF_ERR_HIP, std::string("ikf_create: allocation failed: ") + hipGetErrorString(e));
@@ -270,6 +281,8 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->h_count) (void)hipHostFree(m->h_count);
   if (m->d_split_flag) (void)hipFree(m->d_split_flag);
   if (m->h_split_flag) (void)hipHostFree(m->h_split_flag);
+  if (m->d_arrive) (void)hipFree(m->d_arrive);
+  if (m->h_give_up) (void)hipHostFree(m->h_give_up);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   if (m->tail_event) (void)hipEventDestroy(m->tail_event);
   delete m;
@@ -605,13 +618,17 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_entry = variant - 110;
     return IKF_OK;
   }
+  if (variant == 120 || variant == 121) {  // next subnet's entry phase in the tail of the last hidden contraction: off / on
+    m->fuse_tail = variant - 120;
+    return IKF_OK;
+  }
   if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
     m->gemm_variant = 100;
     m->tile_cfg = variant - 101;
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -667,22 +684,36 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     if (split_cfg_needs_frag(scfg) && m->split_frag_arena == nullptr) scfg = 3;
   }
   const int slots = split ? split_slots(scfg, d.width) : fused_slots(cfg, d.width);
+  // In-launch hand-over (TailSync): the last hidden contraction of subnet s also runs subnet s+1's entry phase, so only the
+  // first subnet of the call has an entry launch.  Taken when every workgroup of that contraction is resident at once.
+  const bool tail = !split && m->fuse_tail != 0 && d.n_hidden >= 2 && NB * 2 > 1 &&
+                    fused_tail_ok(cfg, nr, d.width, d.D, 2 * (d.L1 > d.L2 ? d.L1 : d.L2)) &&
+                    (cfg != fused_skinny_cfg() || frag_image(m, 0, d.n_hidden - 2) != nullptr);
+  int tails_done = 0;
+  bool entry_done = false;  // this subnet's entry phase already ran in the previous subnet's last launch
   PendingCoupling pend{};
   pend.P = nullptr;
   const float* x_src = d_latent + (size_t)r0 * d.D;
   float* xb[2] = {m->xbuf, m->xbuf2};
-  for (int sidx = 0; sidx < 2 * NB; ++sidx) {
+  auto entry_args = [&](int sidx, const PendingCoupling& pc, const float* xs) {
     const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
     const SubnetWeights& w = m->subnets[2 * b + which - 1];
     EntryArgs e{};
-    e.pend = pend;
-    e.x_src = x_src; e.x_dst = xb[sidx & 1];
+    e.pend = pc;
+    e.x_src = xs; e.x_dst = xb[sidx & 1];
     e.M = (int)nr; e.D = d.D; e.L1 = d.L1; e.clamp = d.clamp;
     e.x_off = (which == 1) ? 0 : d.L1; e.n_x = w.n_x;
     e.ps = ps; e.row0 = r0;
     e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
     e.width = d.width; e.slope = d.slope; e.h_out = m->hA; e.split_out = split ? 1 : 0;
     e.split_flag = split ? m->d_split_flag : nullptr;
+    return e;
+  };
+  for (int sidx = 0; sidx < 2 * NB; ++sidx) {
+    const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
+    const SubnetWeights& w = m->subnets[2 * b + which - 1];
+    EntryArgs e = entry_args(sidx, pend, x_src);
+    if (tail && sidx == 0) { e.zero_words = m->d_arrive; e.n_zero = kArriveWords; }
     FusedGemmArgs g{};
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
@@ -691,10 +722,20 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     // chain it pays with the 32x32 tiles (<= 256 rows: 0.56 -> 0.53 ms per call); with the 32x64 tiles (257..512 rows) the
     // one launch takes as long as the two it replaces (18.4 us against 5.5 + 13.0), so those keep the two-launch form
     // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
-    const bool one_launch = !split && (m->fuse_entry == 2 || (m->fuse_entry == 1 && cfg == fused_skinny32_cfg())) &&
+    const bool one_launch = !tail && !split && (m->fuse_entry == 2 || (m->fuse_entry == 1 && cfg == fused_skinny32_cfg())) &&
                             entry_gemm_ok(cfg, nr, d.width, d.D, pend.P ? pend.n_out : 0) &&
                             frag_image(m, 2 * b + which - 1, 0) != nullptr;
-    if (!one_launch) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
+    if (!one_launch && !entry_done) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));
+    entry_done = false;
+    // the pending coupling this subnet leaves behind (its last Linear exists only as partial sums)
+    PendingCoupling mine{};
+    mine.P = m->pbuf;
+    mine.b_last = w.b_last;
+    mine.perm_inv = m->d_perm_inv + (size_t)b * d.D;
+    mine.slot_stride = rows_pad * IKF_PSTRIDE;
+    mine.slots = slots;
+    mine.which = which;
+    mine.n_out = w.n_out;
     float* cur = m->hA;
     float* nxt = m->hB;
     for (int l = 0; l < n_mid; ++l) {
@@ -712,18 +753,25 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
         g.A = cur; g.C = last ? nullptr : nxt; g.W = w.w_mid[l]; g.bias = w.b_mid[l];
         g.Wf = frag_image(m, 2 * b + which - 1, l);
         if (l == 0 && one_launch) IKF_HIP(launch_entry_gemm(w.n_x + d.n_pose, last, cfg, e, g, s));
-        else IKF_HIP(launch_flow_gemm(last, cfg, g, s));
+        else if (last && tail && sidx + 1 < 2 * NB) {
+          // subnet sidx+1's entry phase rides in this launch's tail: its pending coupling is what this launch produces, its
+          // state source is the state this subnet's entry phase published
+          const int b2 = NB - 1 - (sidx + 1) / 2, which2 = 1 + ((sidx + 1) & 1);
+          const EntryArgs e2 = entry_args(sidx + 1, mine, e.x_dst);
+          TailSync ts{};
+          ts.arrive = m->d_arrive;
+          ts.target = (unsigned)(tails_done + 1) * (unsigned)fused_tail_col_tiles(cfg, d.width);
+          ts.give_up = m->h_give_up;
+          ts.n_in = m->subnets[2 * b2 + which2 - 1].n_x + d.n_pose;
+          IKF_HIP(launch_flow_gemm_tail(cfg, g, e2, ts, s));
+          ++tails_done;
+          entry_done = true;
+        } else IKF_HIP(launch_flow_gemm(last, cfg, g, s));
       }
       IKF_HIP(prof_mark(m, s));
       float* tmp = cur; cur = nxt; nxt = tmp;
     }
-    pend.P = m->pbuf;
-    pend.b_last = w.b_last;
-    pend.perm_inv = m->d_perm_inv + (size_t)b * d.D;
-    pend.slot_stride = rows_pad * IKF_PSTRIDE;
-    pend.slots = slots;
-    pend.which = which;
-    pend.n_out = w.n_out;
+    pend = mine;
     x_src = e.x_dst;
   }
   FinalizeArgs f{};
@@ -792,6 +840,15 @@ static ikf_status run_flow_guarded(ikf_model* m, PoseSource ps, const float* d_l
 
 static ikf_status check_ready(ikf_model* m, const char* fn) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, std::string(fn) + ": null model");
+  if (m->h_give_up && *m->h_give_up != 0) {
+    // a workgroup of an EARLIER call gave up waiting for a sibling inside a launch (it was never resident: the device is
+    // shared or partitioned in a way the launcher did not expect).  That call's results are invalid; the hand-over is
+    // switched off for this handle and every later call uses the plain launch boundary.
+    *m->h_give_up = 0;
+    m->fuse_tail = 0;
+    return fail(IKF_ERR_HIP, std::string(fn) + ": an in-launch hand-over of a PREVIOUS call timed out - that call's results are invalid; "
+                                               "the in-launch hand-over is now disabled for this handle, repeat the call");
+  }
   if (!m->loaded)
     return fail(IKF_ERR_NOT_LOADED, "Model weights have not been loaded. Call load_state_dict(...)");
   return IKF_OK;

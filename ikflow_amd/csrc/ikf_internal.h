@@ -102,6 +102,20 @@ struct EntryArgs {      // k_subnet_entry: pending coupling + first Linear of th
   float* h_out;         // [rows_pad][width]  fp32, or the f16 hi/lo split image when split_out != 0
   int split_out;
   int* split_flag;      // split_out: OR'ed with 1 when an activation is non-finite or beyond the f16 range (65504)
+  unsigned* zero_words; // first entry kernel of a call whose later launches hand over inside a launch: words it zeroes
+  int n_zero;           //   (the row tiles' arrival counters, see TailSync), else null / 0
+};
+// Row-tile-local hand-over inside a launch (k_flow_gemm<true, .., FUSE> / k_flow_gemm_skinny<true, 2, FUSE>): the column-tile
+// workgroups of one row tile publish their last-Linear partial sums write-through, arrive on the row tile's counter, wait
+// for their siblings and then run the NEXT subnet's entry phase (pending coupling + their column slice of its first
+// Linear) themselves - the k_subnet_entry launch between two subnets disappears.  Placement-independent: payload stores
+// and loads are agent-scope (sc1), the counter is an agent-scope atomic; needs every workgroup of the launch resident
+// (the launcher only uses it when the grid is at most one workgroup per CU).
+struct TailSync {
+  unsigned* arrive;     // [row tiles] arrival counters, zeroed by the call's first entry kernel
+  unsigned target;      // arrive[tm] once every column tile of this subnet has published: (fused subnets so far + 1) * column tiles
+  int* give_up;         // host-visible word, set non-zero by a workgroup whose wait ran out (a sibling was not resident)
+  int n_in;             // inputs of the next subnet's first Linear (n_x + 7 pose entries)
 };
 struct FusedGemmArgs {
   // contraction C = lrelu(A . W^T + bias), K = N = width
@@ -136,6 +150,11 @@ int fused_slots(int cfg, int width);            // partial-sum slots that config
 int fused_max_slots(int width);
 hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s);
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s);
+// the last hidden contraction of a subnet with the next subnet's entry phase in its tail (e: the entry arguments of the
+// NEXT subnet, its pending coupling = this launch's partial sums)
+bool fused_tail_ok(int cfg, long long rows, int width, int D, int n_out);
+int fused_tail_col_tiles(int cfg, int width);
+hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArgs& e, const TailSync& ts, hipStream_t s);
 // small batches: k_subnet_entry + the first hidden contraction in one launch (k_entry_gemm_skinny)
 bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out);
 hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e, const FusedGemmArgs& a, hipStream_t s);

@@ -235,6 +235,23 @@ int main(int argc, char** argv) {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       printf("k_flow_gemm cfg %d M=%d K=%d: %.2f us/launch  %.1f TFLOP/s  maxerr %.2e\n", cfg, M, K, 1000.0 * ms / iters, flop / (ms / iters * 1e-3) / 1e12, maxerr);
     }
+    if (getenv("IKF_PROBE_PINGPONG")) {  // as in the engine's chain: every launch reads the activation the previous launch wrote, over 48 weight images
+      float* C2; CK(hipMalloc(&C2, (size_t)Mp * N * 4)); CK(hipMemcpy(C2, A, (size_t)Mp * K * 4, hipMemcpyDeviceToDevice));
+      const int NW = 48;
+      float* Wall; CK(hipMalloc(&Wall, (size_t)NW * N * K * 4));
+      for (int w = 0; w < NW; ++w) CK(hipMemcpy(Wall + (size_t)w * N * K, W, (size_t)N * K * 4, hipMemcpyDeviceToDevice));
+      for (int rep = 0; rep < 3; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) {
+          ikf::FusedGemmArgs h = g;
+          h.A = (i & 1) ? C2 : C; h.C = (i & 1) ? C : C2; h.W = Wall + (size_t)(i % NW) * N * K;
+          ikf::launch_flow_gemm(false, cfg, h, 0);
+        }
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("  chain (ping-pong activations, 48 weight images): %.2f us/launch\n", 1000.0 * ms / iters);
+      }
+    }
     unsigned long long* tb; const int nb = 4096;
     CK(hipMalloc(&tb, (size_t)nb * 64 * 8)); CK(hipMemset(tb, 0, (size_t)nb * 64 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(ikf::ikf_trace_buf), &tb, sizeof(tb)));
