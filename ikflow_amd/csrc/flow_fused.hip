@@ -22,6 +22,7 @@ namespace ikf {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4_t __attribute__((ext_vector_type(4)));
 
 // optional in-kernel timeline (tools/gemm_probe.hip builds with -DIKF_TRACE): thread 0 of every workgroup stores the
 // shader clock at a few points of k_flow_gemm into ikf_trace_buf[block][64]
@@ -249,7 +250,10 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
       acc.w = acc.w > 0.f ? acc.w : acc.w * e.slope;
       // h rows are padded to a multiple of 128 (engine scratch): unpredicated
       if (!e.split_out) {
-        reinterpret_cast<floatx4*>(e.h_out + (size_t)(m0 + r) * e.width)[c4] = acc;
+        if (e.wt_stores) {
+          const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(e.h_out, 0, 0x7fffffff, 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4_t, acc), rsH, (unsigned)(((size_t)(m0 + r) * e.width + c4 * 4) * 4), 0, 16);
+        } else reinterpret_cast<floatx4*>(e.h_out + (size_t)(m0 + r) * e.width)[c4] = acc;
       } else {
         // split-32 image: 4 consecutive columns -> 4 hi halves (8 B) and 4 lo halves (8 B, 64 B further on)
         typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -655,7 +659,8 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 #elif defined(IKF_EPI_SC1)     // probes only: write-through (agent-scope) stores instead of write-back ones
           __hip_atomic_store(&g.C[(size_t)row * N + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-          g.C[(size_t)row * N + col] = v;
+          if (g.wt_stores) __hip_atomic_store(&g.C[(size_t)row * N + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else g.C[(size_t)row * N + col] = v;
 #endif
         }
       }
@@ -819,7 +824,9 @@ __device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx
     for (int j = 0; j < 2; ++j) {
       const int r = 2 * kq + j;
       const int row = m0 + (r & 3) + 8 * (r >> 2) + row_h;
-      g.C[(size_t)row * N + n0 + nh * 32 + col_l] = fin[j];  // row-padded buffer: unpredicated
+      // row-padded buffer: unpredicated
+      if (g.wt_stores) __hip_atomic_store(&g.C[(size_t)row * N + n0 + nh * 32 + col_l], fin[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else g.C[(size_t)row * N + n0 + nh * 32 + col_l] = fin[j];
     }
   } else {
     float* T = smem + KS * NH * 16 * 64;  // behind red[] (other waves may still be summing)

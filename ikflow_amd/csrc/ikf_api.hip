@@ -63,6 +63,11 @@ struct ikf_model {
   // k_subnet_entry launch it replaces (r03: +3.6 % per call at 4096 rows, +7.4 % at 512) - kept as a tested,
   // bit-identical opt-in (ikf_set_gemm_variant 121) because it is the priced answer to "hand over inside the launch"
   int fuse_tail = 0;
+  // Activation stores write-through (sc1): the lines go to memory as they are written instead of sitting dirty in the XCD L2s until the
+  // launch's end flushes them (r03, tools/variant_ab.py: 3.261 -> 3.229 ms per call at 4096 rows with the contractions' stores
+  // write-through, 1.831 -> 1.796 at 2048 and 0.721 -> 0.706 at 512 with the entry kernel's too; the entry kernel's 16-byte stores do
+  // not pay at 4096 rows).  bit 0 contractions, bit 1 entry kernel; -1 = by batch size (contractions always, entry kernel <= 2048 rows)
+  int wt_stores = -1;
   unsigned* d_arrive = nullptr;  // [kArriveWords] row-tile arrival counters of the fused tail (zeroed by every call's first entry kernel)
   int* h_give_up = nullptr;      // pinned, device-visible: set by a workgroup whose in-launch wait ran out
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
@@ -618,6 +623,10 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_entry = variant - 110;
     return IKF_OK;
   }
+  if (variant >= 130 && variant <= 134) {  // write-through activation stores: none / contractions / entry kernel / both / by batch size
+    m->wt_stores = variant == 134 ? -1 : variant - 130;
+    return IKF_OK;
+  }
   if (variant == 120 || variant == 121) {  // next subnet's entry phase in the tail of the last hidden contraction: off / on
     m->fuse_tail = variant - 120;
     return IKF_OK;
@@ -628,7 +637,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -707,6 +716,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
     e.width = d.width; e.slope = d.slope; e.h_out = m->hA; e.split_out = split ? 1 : 0;
     e.split_flag = split ? m->d_split_flag : nullptr;
+    e.wt_stores = m->wt_stores < 0 ? (nr <= 2048 ? 1 : 0) : (m->wt_stores >> 1) & 1;
     return e;
   };
   for (int sidx = 0; sidx < 2 * NB; ++sidx) {
@@ -716,6 +726,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     if (tail && sidx == 0) { e.zero_words = m->d_arrive; e.n_zero = kArriveWords; }
     FusedGemmArgs g{};
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
+    g.wt_stores = m->wt_stores < 0 ? 1 : (m->wt_stores & 1);
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
     const int n_mid = d.n_hidden - 1;
     // small batches: the entry kernel and the first hidden contraction run as one launch (k_entry_gemm_skinny).  In the

@@ -102,6 +102,7 @@ struct EntryArgs {      // k_subnet_entry: pending coupling + first Linear of th
   float* h_out;         // [rows_pad][width]  fp32, or the f16 hi/lo split image when split_out != 0
   int split_out;
   int* split_flag;      // split_out: OR'ed with 1 when an activation is non-finite or beyond the f16 range (65504)
+  int wt_stores;        // activation stores write-through (sc1): nothing is left dirty in the L2s for the launch's end to flush
   unsigned* zero_words; // first entry kernel of a call whose later launches hand over inside a launch: words it zeroes
   int n_zero;           //   (the row tiles' arrival counters, see TailSync), else null / 0
 };
@@ -126,6 +127,7 @@ struct FusedGemmArgs {
   float* C;           // [rows_pad][N]  (unused when the epilogue reduces to partials)
   int M, N, K;
   float slope;
+  int wt_stores;      // activation stores write-through (sc1), see EntryArgs
   // partial-sum epilogue: P_out[slot][row][o] = sum over the tile's columns of lrelu(...)[row][col] * w_last[o][col]
   const float* w_last;  // [n_out][N]
   int n_out;

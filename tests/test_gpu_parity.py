@@ -1363,6 +1363,26 @@ def test_in_launch_entry_phase_equals_entry_launches(kw):
     assert torch.equal(one, s.generate_ik_solutions(poses[0].to(DEV), n=400, latent=lat[:400].to(DEV)))
 
 
+def test_activation_store_policy_does_not_change_results():
+    """ikf_set_gemm_variant 130..134: the hidden activations leave the contractions / the entry kernel with write-back or
+    write-through (sc1) stores - a cache policy, so every setting must give identical bits at every tile configuration."""
+    robot, hp, lay, sd = custom_model(nb_nodes=3, dim=7, n_hidden=3, width=1024, seed=41)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    _, poses = reachable_poses(robot, 4096, 101)
+    lat = latents(4096, lay.dim, 102)
+    try:
+        for n in (5, 200, 300, 512, 700, 1024, 2048, 2049, 4096):
+            P, L = poses[:n].to(DEV), lat[:n].to(DEV)
+            outs = []
+            for code in (130, 131, 132, 133, 134):
+                eng.set_gemm_variant(code)
+                outs.append(s.generate_ik_solutions(P, latent=L))
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), n
+    finally:
+        eng.set_gemm_variant(134)
+
+
 def test_hip_path_against_the_reference_statement_fixtures():
     """tests/golden/ref_exact_loop.npz = outputs of the reference's own `generate_ik_solutions` / `_run_inference` and
     `generate_exact_ik_solutions` / `_generate_exact_ik_solutions` statements (executed over the oracle's flow and kinematics by
