@@ -225,10 +225,12 @@ def cpu_baseline(sd, layout, robot_name, poses_cpu, latent_cpu, budget_s):
     SURVEY 8(d) asks for the all-physical-cores figure and the 1-thread figure: both are timed, together with torch's default
     (= all logical cores, what the reference would run with) and 16 / 32 / 64 threads; `value` is the BEST of them with the thread
     count that gave it.  The 1-thread pass runs on the first 512 rows of the batch (a full 4096-row pass takes ~10 s on one core).
-    Why more threads lose (profiles/r03_cpu_thread_scaling.json, tools/cpu_thread_scaling.py): one [4096 x 1024].[1024 x 1024] layer
-    is 8.6 GFLOP - 67 MFLOP (a millisecond) per thread at 128 threads - and the 12-block chain has ~390 small ops between them, so the
-    per-op fork/join of the intra-op pool across two sockets and the cross-socket reads of the 4 MB weight matrices outweigh the
-    arithmetic; the GEMM alone stops scaling at about a quarter of the cores."""
+    Why more threads lose (profiles/r03_cpu_thread_scaling.json, tools/cpu_thread_scaling.py, 2 x 64-core EPYC 9575F): the
+    [4096 x 1024].[1024 x 1024] GEMM alone keeps scaling (1.8 TFLOP/s at 16 threads, 5.5 at 128), but the pass does not - torch.profiler
+    at 128 threads: addmm 455 ms of a 1.9 s pass, the rest is the ~390 small ops, each paying the 128-thread parallel region
+    (aten::atan on a [4096 x 4] tensor: 11 ms per call; copy_ 3 ms, index 15 ms), against 271 ms of addmm in a 0.96 s pass at 16
+    threads where the same small ops cost microseconds.  The all-cores figure is fork/join overhead of the intra-op pool over two
+    sockets (shared with the host's other tenants), not arithmetic."""
     from oracle import flow_oracle as fo
 
     n = poses_cpu.shape[0]
@@ -273,9 +275,10 @@ def cpu_baseline(sd, layout, robot_name, poses_cpu, latent_cpu, budget_s):
         "all_physical_cores": {"cores": phys, "value": rates.get(phys)} if phys else None,
         "all_logical_cores": {"cores": default_threads, "value": rates.get(default_threads)},
         "sample": f"passes of the same B={n} batch through oracle/flow_oracle.py (torch-CPU fp32); " + "; ".join(notes)
-                  + f"; host has {os.cpu_count()} logical / {phys} physical cores; `value` = the best thread count. More threads lose because "
-                    "a layer is only 8.6 GFLOP and the chain has ~390 small ops: intra-op fork/join over two sockets and cross-socket "
-                    "weight reads dominate (tools/cpu_thread_scaling.py, profiles/r03_cpu_thread_scaling.json)",
+                  + f"; host has {os.cpu_count()} logical / {phys} physical cores; `value` = the best thread count. More threads lose on the "
+                    "path's ~390 small ops, not on the GEMMs: torch.profiler at 128 threads shows addmm 455 ms of a 1.9 s pass and e.g. 11 ms "
+                    "per aten::atan call on a [4096 x 4] tensor (the 128-thread parallel region over two sockets), against 271 ms of addmm in "
+                    "a 0.96 s pass at 16 threads (tools/cpu_thread_scaling.py, profiles/r03_cpu_thread_scaling.json)",
     }
 
 
@@ -637,6 +640,10 @@ def main():
             "value_guard_off": world * B * n2 / dt3, "overflow_flag_after_guard_off_run": bool(pending),
             "max_abs_diff_vs_f32_path": float((sol2 - sol).abs().max().item()),
             "note": "opt-in IKFlowSolver.set_precision('f16x3'): a = hi + lo/2048 operand split, 3 v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate",
+            "bound": "power",
+            "bound_evidence": "profiles/r03_clock_power.json (amdsmi gpu_metrics sampled at 20 Hz through 2.5 s sustained runs, tools/clock_power_probe.py): "
+                              "f16x3 holds 1.77-1.89 GHz at 1.27 kW with the package-power tracker limiting 27 % of the time; the f32 mode holds "
+                              "2.39 GHz at 1.26 kW (limited 9 % of the time)",
         }
     if use_dist and mode == "weak" and not args.no_scaling_extras and not TEST_BACKEND:
         # the two strong-scaling readings of the metric, measured in the same launch (all ranks take part): a FIXED global batch of

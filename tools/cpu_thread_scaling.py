@@ -82,8 +82,22 @@ def main():
                      "chain_solutions_per_s": nr / t_chain,
                      "chain_share_of_48_gemms": 48 * t_gemm * (nr / n) / t_chain})
         print(json.dumps(rows[-1]), flush=True)
+    # where the time goes at the best and at the default thread count: torch.profiler, self CPU time per operator over one pass
+    ops = {}
+    from torch.profiler import ProfilerActivity, profile
+
+    for th in sorted({16, default_threads}):
+        torch.set_num_threads(th)
+        fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
+        t0 = time.perf_counter()
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
+        wall = time.perf_counter() - t0
+        rows_p = sorted(prof.key_averages(), key=lambda e: -e.self_cpu_time_total)[:8]
+        ops[str(th)] = {"wall_s": wall, "top_self_cpu": [{"op": e.key, "calls": e.count, "self_ms": e.self_cpu_time_total / 1e3} for e in rows_p]}
+        print(th, "threads:", wall, [(e.key, e.count, round(e.self_cpu_time_total / 1e3, 1)) for e in rows_p[:6]], flush=True)
     torch.set_num_threads(default_threads)
-    doc = {"host": topo, "torch_default_threads": default_threads, "torch_parallel_info": torch.__config__.parallel_info().splitlines()[:8],
+    doc = {"host": topo, "profiler_top_ops": ops, "torch_default_threads": default_threads, "torch_parallel_info": torch.__config__.parallel_info().splitlines()[:8],
            "rows": rows,
            "reading": "gemm_gflops peaks at a fraction of the cores and falls beyond it; chain_share_of_48_gemms shows how much of the "
                       "pass is GEMM time at that thread count - the remainder is the per-op overhead of the ~390 small ops, which grows "
