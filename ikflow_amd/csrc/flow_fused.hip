@@ -1206,6 +1206,316 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e
   skinny_tail<EPI_RED, NH>(g, acc, smem, m0, n0, t, lane, wave, nh, kq);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// <= 128 rows: tiles of 16 rows x 32 columns on v_mfma_f32_16x16x4_f32 (r03).  With 32-row tiles a batch of <= 128 rows gives at
+// most 128 workgroups, and each of them carries 512 MFMAs (3.4 us on its CU's four SIMDs) while the other half of the chip idles:
+// the launch is matrix-pipe bound on too few CUs.  16-row tiles double the workgroups (8 row tiles x 32 column tiles = 256 at 128
+// rows) and halve everything a workgroup repeats per row: its K loop, and in the one-launch head its copy of the first Linear.
+//   * MFMA shape: D[16 x 16] += A[16 x 4] . B[4 x 16]; lane l feeds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16] and gets
+//     D[i = 4 * (l / 16) + v][j = l % 16] in accumulator register v.  A = activation rows, B = weight columns: a lane reads four
+//     consecutive k of its row / column at k offset 4 * (l / 16) of the wave's 16-k slice; component c feeds MFMA c (the same k
+//     permutation on both sides, as in the 32x32 kernels).  Two column blocks per tile share the A fragment.
+//   * the W fragments come from the SAME fragment-major image as the 32x32 kernels' (k_wfrag_pack): element (kk, lane32) of a
+//     (32-column tile, k tile, k slice) holds W[col = lane32 % 32][k = 8 kk + 4 (lane32 / 32) ..]; lane l of column block cb wants
+//     col = 16 cb + l % 16, k = 4 (l / 16), i.e. element (kk = l / 32, lane32 = 16 cb + l % 16 + 32 ((l / 16) % 2)): a wave's fetch
+//     is four 256-byte runs of the 2 KB the 32x32 kernel fetches as one.
+//   * partial-sum slots stay 32 columns wide (one per workgroup): the pending coupling reads the same 32 slots at width 1024.
+// The tile's summation order differs from the 32x32 kernels' (k slices as before, but the last Linear's 32 columns in one MFMA
+// chain): results agree with the other tile shapes to rounding, like every change of tile shape.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S16_ROWS = 16;
+constexpr size_t skinny16_tail_lds() { return sizeof(float) * ((size_t)KKS * 2 * 4 * 64 + (size_t)(S16_ROWS + 16) * (32 + 4)); }
+constexpr size_t skinny16_lds() {
+  return skinny16_tail_lds() > sizeof(float) * 2 * S16_ROWS * (KBK + 4) ? skinny16_tail_lds() : sizeof(float) * 2 * S16_ROWS * (KBK + 4);
+}
+constexpr size_t entry_gemm16_lds(int K) {
+  return sizeof(float) * ((size_t)S16_ROWS * (K + 4) + 2 * S16_ROWS * ROWBUF + S16_ROWS * EG_ULD);
+}
+#define IKF_MFMA16(FA, FB, ACC)                                                      \
+  {                                                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.x, FB.x, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.y, FB.y, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.z, FB.z, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.w, FB.w, ACC, 0, 0, 0);            \
+  }
+// byte offset of lane l's W fragment of column block cb inside a (32-column tile, k tile) of the fragment-major image
+__device__ __forceinline__ unsigned wfrag16_off(int kq, int lane, int cb) {
+  const int g = lane >> 4;
+  return (unsigned)(((kq * KKG + (g >> 1)) * 64 + cb * 16 + (lane & 15) + 32 * (g & 1)) * 16);
+}
+
+// tail of the 16-row kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.  Call after a barrier
+// that ends every LDS read of the loop.  acc[cb][v] = tile[row = 4 * (lane / 16) + v][col = 16 cb + lane % 16] over this wave's k slice.
+template <bool EPI_RED>
+__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[2], float* smem, int m0, int n0, int t,
+                                              int lane, int kq) {
+  constexpr int BN = 32, LDT = BN + 4, NT = KKS * 64;
+  const int N = g.N;
+  float* red = smem;  // [KKS][2][4][64]
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[((kq * 2 + cb) * 4 + v) * 64 + lane] = acc[cb][v];
+  __syncthreads();
+  // wave kq finishes accumulator register (cb = kq / 4, v = kq % 4) of every lane: the k slices in fixed order 0, 1, ..
+  const int cb = kq >> 2, v = kq & 3;
+  float fin = 0.f;
+#pragma unroll
+  for (int q = 0; q < KKS; ++q) fin += red[((q * 2 + cb) * 4 + v) * 64 + lane];
+  const int row = 4 * (lane >> 4) + v, col = cb * 16 + (lane & 15);
+  fin += g.bias[n0 + col];
+  fin = fin > 0.f ? fin : fin * g.slope;
+  if constexpr (!EPI_RED) {
+    float* dst = g.C + (size_t)(m0 + row) * N + n0 + col;  // row-padded buffer: unpredicated
+    if (g.wt_stores) __hip_atomic_store(dst, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *dst = fin;
+  } else {
+    float* T = smem + KKS * 2 * 4 * 64;  // [16][LDT], behind red[] (other waves may still be summing)
+    float* Wl = T + S16_ROWS * LDT;      // [16][LDT]: w_last rows (zero beyond n_out), this tile's 32 columns
+    T[row * LDT + col] = fin;
+    for (int idx = t; idx < 16 * (BN / 4); idx += NT) {
+      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      floatx4 w = {0.f, 0.f, 0.f, 0.f};
+      if (o < g.n_out) w = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = w;
+    }
+    __syncthreads();
+    if (kq == 0) {  // one wave: P[row][o] = sum over the tile's 32 columns of h[row][col] * w_last[o][col], one MFMA chain
+      floatx4 pacc = {0.f, 0.f, 0.f, 0.f};
+      const int gq = lane >> 4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(T + (lane & 15) * LDT + 16 * h + 4 * gq);
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(Wl + (lane & 15) * LDT + 16 * h + 4 * gq);
+        IKF_MFMA16(a4, b4, pacc)
+      }
+      // pacc[v] = P[row = 4 * gq + v][o = lane % 16]
+      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + 4 * gq) * IKF_PSTRIDE + (lane & 15);
+#pragma unroll
+      for (int vv = 0; vv < 4; ++vv) pout[vv * IKF_PSTRIDE] = pacc[vv];
+    }
+  }
+}
+
+// hidden contraction, 16 x 32 tiles: A rows through two LDS stages (one barrier per k tile), W fragments two k tiles ahead
+// DEEP (K <= 8 k tiles): the workgroup's whole operand stream - 8 x 16 B of A rows per thread, 16 x 16 B of W fragments per lane - is
+// requested up front, tile by tile (sched_barrier keeps that order: tile 0 must not queue behind the rest).  A k tile is only 0.2 us of
+// matrix-pipe time per SIMD here, so two tiles of lead (0.4 us) no longer cover a memory round trip (1 - 2 us).
+constexpr int kDeepTiles = 8;
+template <bool EPI_RED, bool DEEP>
+__global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g) {
+  constexpr int BM = S16_ROWS, BN = 32, BK = KBK, NT = KKS * 64, LDK = BK + 4, KQ4 = BK / 4, STAGE = BM * LDK;
+  static_assert(BM * KQ4 == NT, "one float4 of the A tile per thread per stage");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int M = g.M, N = g.N, K = g.K;
+  const int tiles_n = N / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, kq = __builtin_amdgcn_readfirstlane(t >> 6);
+  floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int arow = t / KQ4, ac4 = t - arow * KQ4;
+  int gr = m0 + arow;
+  gr = gr < M ? gr : M - 1;
+  const unsigned aoff = ((unsigned)gr * (unsigned)K + ac4 * 4) * 4u;
+  const int ldst = arow * LDK + ac4 * 4;
+  constexpr int WTILE = KKS * KKG * 256;
+  const int KT = K / BK;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
+  const unsigned wtile0 = (unsigned)tn * KT;
+  const unsigned woff0 = wfrag16_off(kq, lane, 0), woff1 = wfrag16_off(kq, lane, 1);
+  const int fragA = (lane & 15) * LDK + kq * KKW + (lane >> 4) * 4;
+#define IK6_LDA(kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
+#define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
+  if constexpr (DEEP) {
+    floatx4 aall[kDeepTiles], wall[kDeepTiles][2];
+#pragma unroll
+    for (int kt = 0; kt < kDeepTiles; ++kt) {  // unconditional loads (clamped index past the last tile): the compiler counts them
+      const int kc = kt < KT ? kt : KT - 1;
+      aall[kt] = IK6_LDA(kc);
+      wall[kt][0] = IK6_LDW(woff0, kc);
+      wall[kt][1] = IK6_LDW(woff1, kc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    *reinterpret_cast<floatx4*>(smem + ldst) = aall[0];
+    __syncthreads();
+    floatx4 fa = *reinterpret_cast<const floatx4*>(smem + fragA);
+#pragma unroll
+    for (int kt = 0; kt < kDeepTiles; ++kt) {
+      if (kt < KT) {  // uniform
+        const int nxt = (kt & 1) ^ 1;
+        if (kt + 1 < kDeepTiles) *reinterpret_cast<floatx4*>(smem + nxt * STAGE + ldst) = aall[kt + 1 < kDeepTiles ? kt + 1 : kt];
+        IKF_MFMA16(fa, wall[kt][0], acc[0])
+        IKF_MFMA16(fa, wall[kt][1], acc[1])
+        __syncthreads();
+        fa = *reinterpret_cast<const floatx4*>(smem + nxt * STAGE + fragA);
+      }
+    }
+  } else {
+    floatx4 rg = IK6_LDA(0);
+    floatx4 wc0 = IK6_LDW(woff0, 0), wc1 = IK6_LDW(woff1, 0);
+    *reinterpret_cast<floatx4*>(smem + ldst) = rg;
+    const int k1 = KT > 1 ? 1 : 0;
+    rg = IK6_LDA(k1);
+    floatx4 wn0 = IK6_LDW(woff0, k1), wn1 = IK6_LDW(woff1, k1);
+    __syncthreads();
+    floatx4 fa = *reinterpret_cast<const floatx4*>(smem + fragA);
+    // iteration kt: A tile kt+1 (in rg) -> the other stage, tile kt+2 requested; MFMAs of tile kt; barrier; fragment of tile kt+1.
+    // Branch-free: prefetches past the last tile re-read the last tile (clamped index), the extra LDS image is never consumed.
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1, nxt = cur ^ 1;
+      const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
+      *reinterpret_cast<floatx4*>(smem + nxt * STAGE + ldst) = rg;
+      rg = IK6_LDA(k2);
+      IKF_MFMA16(fa, wc0, acc[0])
+      IKF_MFMA16(fa, wc1, acc[1])
+      wc0 = wn0;
+      wc1 = wn1;
+      wn0 = IK6_LDW(woff0, k2);
+      wn1 = IK6_LDW(woff1, k2);
+      __syncthreads();
+      fa = *reinterpret_cast<const floatx4*>(smem + nxt * STAGE + fragA);
+    }
+  }
+#undef IK6_LDA
+#undef IK6_LDW
+  __syncthreads();  // all fragment reads done before the stage area is reused
+  skinny16_tail<EPI_RED>(g, acc, smem, m0, n0, t, lane, kq);
+}
+
+// one-launch subnet head, 16 x 32 tiles: pending coupling of the tile's 16 rows, the whole first Linear + LeakyReLU of those rows
+// on the matrix pipe into a resident LDS tile, barrier-free K loop (see k_entry_gemm_skinny).
+template <bool EPI_RED, bool DEEP>
+__global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
+  constexpr int BN = 32, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS;
+  constexpr int BPW_MAX = 8;  // first-Linear 16-column blocks per wave at K = 1024
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = g.K, N = g.N;
+  const int LDKF = K + 4;
+  float* A_full = smem;                    // [R][K + 4]; reused by the tail after the loop
+  float* cat = smem + (size_t)R * LDKF;    // [R][ROWBUF]
+  float* sums = cat + R * ROWBUF;
+  float* U = sums + R * ROWBUF;            // [R][EG_ULD]
+  const int tiles_n = N / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * R, n0 = tn * BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int kq = wave;
+  const int M = e.M, D = e.D;
+  const int gq = lane >> 4, cl = lane & 15;
+
+  PendingLoads<(R * ROWBUF + NT - 1) / NT> pl;
+  pending_issue_loads<NT, R>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);  // the critical path's loads go first
+
+  constexpr int WTILE = KKS * KKG * 256;
+  const int KT = K / BK;
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
+  const unsigned wtile0 = (unsigned)tn * KT;
+  const unsigned woff0 = wfrag16_off(kq, lane, 0), woff1 = wfrag16_off(kq, lane, 1);
+#define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
+  floatx4 wc0, wc1, wn0, wn1;
+  floatx4 wall[DEEP ? kDeepTiles : 1][2];
+  if constexpr (DEEP) {  // the whole W-fragment stream now: it has the pending and first-Linear phases to arrive in
+#pragma unroll
+    for (int kt = 0; kt < kDeepTiles; ++kt) {
+      const int kc = kt < KT ? kt : KT - 1;
+      wall[kt][0] = IK6_LDW(woff0, kc);
+      wall[kt][1] = IK6_LDW(woff1, kc);
+    }
+  } else {
+    wc0 = IK6_LDW(woff0, 0);
+    wc1 = IK6_LDW(woff1, 0);
+    const int k1 = KT > 1 ? 1 : 0;
+    wn0 = IK6_LDW(woff0, k1);
+    wn1 = IK6_LDW(woff1, k1);
+  }
+
+  // first-Linear operands of this wave's 16-column blocks: MFMA "A" = W1^T (i = column of the block), "B" = the input rows
+  // (j = row), so that a lane's four accumulator registers are four CONSECUTIVE columns of one row
+  const int bpw = (K / 16) / NW;  // launcher: divides, <= BPW_MAX
+  float wb[BPW_MAX][4];
+  floatx4 bias4[BPW_MAX];
+#pragma unroll
+  for (int i = 0; i < BPW_MAX; ++i) {
+    const int cb = i < bpw ? wave * bpw + i : 0;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int k = 4 * s4 + gq;
+      const float v = e.w1t[(size_t)(k < n_in ? k : 0) * e.width + cb * 16 + cl];
+      wb[i][s4] = k < n_in ? v : 0.f;
+    }
+    floatx4 bv = *reinterpret_cast<const floatx4*>(e.b1 + cb * 16 + 4 * gq);
+    if (e.ps.softflow != 0.0f) bv += e.ps.softflow * *reinterpret_cast<const floatx4*>(e.w1soft + cb * 16 + 4 * gq);
+    bias4[i] = bv;
+  }
+  const int ur = t / ROWBUF, uk = t % ROWBUF;
+  float pose_v = 0.f;
+  if (t < R * ROWBUF && uk >= e.n_x && uk < n_in) {
+    int gr = m0 + ur;
+    gr = gr < M ? gr : M - 1;
+    const long long grow = e.row0 + gr;
+    const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
+    const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
+    pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
+  }
+  finish_pending_rows<NT, R>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
+  if (t < R * ROWBUF) {
+    if (tn == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
+    U[ur * EG_ULD + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;  // 0 beyond n_in
+  }
+  __syncthreads();
+  {
+    float ua[4];  // "B" fragment of step s: U[row = lane % 16][k = 4 s + lane / 16]
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) ua[s4] = U[cl * EG_ULD + 4 * s4 + gq];
+#pragma unroll
+    for (int i = 0; i < BPW_MAX; ++i) {
+      if (i < bpw) {
+        floatx4 a1 = bias4[i];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+          if (4 * s4 < n_in) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s4], ua[s4], a1, 0, 0, 0);  // k past n_in: 0 * 0
+        a1.x = a1.x > 0.f ? a1.x : a1.x * e.slope;
+        a1.y = a1.y > 0.f ? a1.y : a1.y * e.slope;
+        a1.z = a1.z > 0.f ? a1.z : a1.z * e.slope;
+        a1.w = a1.w > 0.f ? a1.w : a1.w * e.slope;
+        // a1[v] = h1[row = lane % 16][column = 16 (wave bpw + i) + 4 (lane / 16) + v]
+        *reinterpret_cast<floatx4*>(A_full + (size_t)cl * LDKF + (wave * bpw + i) * 16 + 4 * gq) = a1;
+      }
+    }
+  }
+  __syncthreads();
+  floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const float* fragA = A_full + (size_t)cl * LDKF + kq * KKW + gq * 4;
+  if constexpr (DEEP) {
+#pragma unroll
+    for (int kt = 0; kt < kDeepTiles; ++kt) {
+      if (kt < KT) {  // uniform; barrier-free: A fragments from the resident tile
+        const floatx4 fa = *reinterpret_cast<const floatx4*>(fragA + kt * BK);
+        IKF_MFMA16(fa, wall[kt][0], acc[0])
+        IKF_MFMA16(fa, wall[kt][1], acc[1])
+      }
+    }
+  } else {
+    for (int kt = 0; kt < KT; ++kt) {  // barrier-free: A fragments from the resident tile, W fragments two tiles ahead
+      const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
+      const floatx4 fa = *reinterpret_cast<const floatx4*>(fragA + kt * BK);
+      IKF_MFMA16(fa, wc0, acc[0])
+      IKF_MFMA16(fa, wc1, acc[1])
+      wc0 = wn0;
+      wc1 = wn1;
+      wn0 = IK6_LDW(woff0, k2);
+      wn1 = IK6_LDW(woff1, k2);
+    }
+  }
+#undef IK6_LDW
+  __syncthreads();  // every wave is done with A_full before the tail reuses the memory
+  skinny16_tail<EPI_RED>(g, acc, smem, m0, n0, t, lane, kq);
+}
+#undef IKF_MFMA16
+
 // fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
 //   (((tn32*KT + kt)*KKS + kq)*KKG + kk)*64 + lane  <-  W[tn32*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
 // (per 32-column tile and k tile: 8 k-slices x 2 MFMA groups x 64 lanes; a wave's fetch for one stage is 2 KB contiguous)
@@ -1264,8 +1574,36 @@ static hipError_t launch_entry_gemm_t(const EntryArgs& e, const FusedGemmArgs& a
   return hipGetLastError();
 }
 
+int g_deep16 = 1;  // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole stream
+template <bool EPI_RED, bool DEEP>
+static hipError_t launch_skinny16(const FusedGemmArgs& a, hipStream_t s) {
+  constexpr size_t smem = skinny16_lds();
+  auto kern = k_flow_gemm_skinny16<EPI_RED, DEEP>;
+  static bool lds_ok[64] = {};
+  if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
+  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / 32);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, a);
+  return hipGetLastError();
+}
+template <bool EPI_RED, bool DEEP>
+static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a, int n_in, hipStream_t s) {
+  size_t smem = entry_gemm16_lds(a.K);
+  if (smem < skinny16_tail_lds()) smem = skinny16_tail_lds();
+  auto kern = k_entry_gemm_skinny16<EPI_RED, DEEP>;
+  static bool lds_ok[64] = {};
+  if (hipError_t err = ensure_dynamic_lds(kern, (size_t)160 * 1024, lds_ok); err != hipSuccess) return err;
+  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / 32);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, e, a, n_in);
+  return hipGetLastError();
+}
+
 // true when the first hidden contraction of a subnet can run as k_entry_gemm_skinny for this batch
 bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out) {
+  if (cfg == 9) {  // kSkinny16Cfg: 16 x 32 tiles
+    const long long tiles = ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32);
+    return tiles <= 512 && width <= 2048 && width % (2 * KBK) == 0 && (width / 16) % KKS == 0 && (width / 16) / KKS <= 8 &&
+           D <= ROWBUF && n_out <= ROWBUF;  // (its 69 KB of LDS at width 1024 lets two workgroups share a CU)
+  }
   if (cfg != 4 && cfg != 6) return false;  // kSkinnyCfg / kSkinny32Cfg
   const int NH = cfg == 4 ? 2 : 1;
   const int NW = NH * KKS;
@@ -1278,6 +1616,11 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
   if (!entry_gemm_ok(cfg, a.M, a.N, e.D, e.pend.n_out) || a.K != a.N || a.Wf == nullptr || a.n_out > 16 || n_in > ROWBUF - 1 ||
       e.width != a.K)
     return hipErrorInvalidValue;
+  if (cfg == 9) {
+    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
+      return epi_red ? launch_entry_gemm16<true, true>(e, a, n_in, s) : launch_entry_gemm16<false, true>(e, a, n_in, s);
+    return epi_red ? launch_entry_gemm16<true, false>(e, a, n_in, s) : launch_entry_gemm16<false, false>(e, a, n_in, s);
+  }
   if (cfg == 4) return epi_red ? launch_entry_gemm_t<true, 2>(e, a, n_in, s) : launch_entry_gemm_t<false, 2>(e, a, n_in, s);
   return epi_red ? launch_entry_gemm_t<true, 1>(e, a, n_in, s) : launch_entry_gemm_t<false, 1>(e, a, n_in, s);
 }
@@ -1285,10 +1628,14 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSkinnyCfg = 4;    // k_flow_gemm_skinny<.., 2>: 32x64 tiles
 constexpr int kSkinny32Cfg = 6;  // k_flow_gemm_skinny<.., 1>: 32x32 tiles (5 is the 4-wave probe of the large tile)
+constexpr int kSkinny16Cfg = 9;  // k_flow_gemm_skinny16: 16x32 tiles on v_mfma_f32_16x16x4_f32 (<= 128 rows)
+int g_skinny16 = 1;              // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles
 int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_skinny32_cfg() { return kSkinny32Cfg; }
+int fused_skinny16_cfg() { return kSkinny16Cfg; }
 int fused_pick_cfg(long long rows, int width) {
   if (width % KBN == 0 && width % (2 * KBK) == 0) {
+    if (rows <= 128 && g_skinny16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32) <= 256) return kSkinny16Cfg;
     if (rows <= 256) return kSkinny32Cfg;
     if (rows <= 512) return kSkinnyCfg;
     if (rows <= 768) return kSkinny32Cfg;  // three co-resident 32x32 workgroups per CU: 1.00 ms against 1.06 (64x64 tiles)
@@ -1312,7 +1659,7 @@ int fused_pick_cfg(long long rows, int width) {
   return -1;
 }
 // partial-sum slots of the last Linear: one per 64 columns, except the 32-column small-batch tiles (half slots)
-int fused_slots(int cfg, int width) { return cfg == kSkinny32Cfg ? width / 32 : width / 64; }
+int fused_slots(int cfg, int width) { return (cfg == kSkinny32Cfg || cfg == kSkinny16Cfg) ? width / 32 : width / 64; }
 int fused_max_slots(int width) { return width / 32; }
 const char* fused_kernel_name() { return "k_flow_gemm"; }
 
@@ -1365,6 +1712,11 @@ hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArg
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
+  if (cfg == kSkinny16Cfg) {
+    if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
+    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK) return epi_red ? launch_skinny16<true, true>(a, s) : launch_skinny16<false, true>(a, s);
+    return epi_red ? launch_skinny16<true, false>(a, s) : launch_skinny16<false, false>(a, s);
+  }
   if (cfg == kSkinnyCfg || cfg == kSkinny32Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
     if (cfg == kSkinnyCfg) return epi_red ? launch_skinny<true, 2>(a, s) : launch_skinny<false, 2>(a, s);

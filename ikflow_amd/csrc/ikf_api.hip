@@ -623,6 +623,14 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_entry = variant - 110;
     return IKF_OK;
   }
+  if (variant == 152 || variant == 153) {  // 16-row kernels: whole operand stream up front off / on (process-wide probe / test switch)
+    g_deep16 = variant - 152;
+    return IKF_OK;
+  }
+  if (variant == 150 || variant == 151) {  // <= 128 rows on 16x32 tiles (v_mfma_f32_16x16x4_f32): off / on
+    g_skinny16 = variant - 150;             // (process-wide: a probe / test switch, not a per-handle setting)
+    return IKF_OK;
+  }
   if (variant >= 130 && variant <= 134) {  // write-through activation stores: none / contractions / entry kernel / both / by batch size
     m->wt_stores = variant == 134 ? -1 : variant - 130;
     return IKF_OK;
@@ -631,13 +639,18 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_tail = variant - 120;
     return IKF_OK;
   }
+  if (variant == 160) {  // fused pipeline with the 16x32 small-batch tiles forced (tile config 9)
+    m->gemm_variant = 100;
+    m->tile_cfg = 9;
+    return IKF_OK;
+  }
   if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
     m->gemm_variant = 100;
     m->tile_cfg = variant - 101;
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -733,7 +746,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     // chain it pays with the 32x32 tiles (<= 256 rows: 0.56 -> 0.53 ms per call); with the 32x64 tiles (257..512 rows) the
     // one launch takes as long as the two it replaces (18.4 us against 5.5 + 13.0), so those keep the two-launch form
     // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
-    const bool one_launch = !tail && !split && (m->fuse_entry == 2 || (m->fuse_entry == 1 && cfg == fused_skinny32_cfg())) &&
+    const bool one_launch = !tail && !split &&
+                            (m->fuse_entry == 2 || (m->fuse_entry == 1 && (cfg == fused_skinny32_cfg() || cfg == fused_skinny16_cfg()))) &&
                             entry_gemm_ok(cfg, nr, d.width, d.D, pend.P ? pend.n_out : 0) &&
                             frag_image(m, 2 * b + which - 1, 0) != nullptr;
     if (!one_launch && !entry_done) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));

@@ -209,6 +209,9 @@ hipError_t launch_wfrag_pack_split(const void* Wsplit, int N, int K, void* out, 
 void split32_pack_host(const float* src, int rows, int K, uint16_t* dst);  // host-side packer (probe tool)
 int fused_skinny_cfg();
 int fused_skinny32_cfg();
+int fused_skinny16_cfg();
+extern int g_deep16;    // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole operand stream
+extern int g_skinny16;  // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles
 hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream_t s);
 hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, int* d_flag, hipStream_t s);
 const char* split_kernel_name();

@@ -1363,6 +1363,58 @@ def test_in_launch_entry_phase_equals_entry_launches(kw):
     assert torch.equal(one, s.generate_ik_solutions(poses[0].to(DEV), n=400, latent=lat[:400].to(DEV)))
 
 
+@pytest.mark.parametrize("kw", [
+    dict(nb_nodes=3, dim=7, n_hidden=3, width=1024),                          # the released shape
+    dict(nb_nodes=2, dim=9, n_hidden=2, width=256),                           # TINY's: head and last contraction are one launch
+    dict(nb_nodes=2, dim=10, n_hidden=4, width=768, robot_name="fetch_arm"),  # a middle contraction (stores its activation)
+    dict(nb_nodes=2, dim=8, n_hidden=3, width=1280, robot_name="fetch"),      # too wide for the one-launch head: entry kernel + 16-row contractions
+    dict(nb_nodes=2, dim=7, n_hidden=3, width=512, softflow=False, sigmoid=True),
+])
+def test_sixteen_row_tiles_for_small_batches(kw):
+    """<= 128 rows run on 16 x 32 tiles (v_mfma_f32_16x16x4_f32; ikf_set_gemm_variant 151, the default) instead of 32 x 32 (150): twice
+    the workgroups, half the matrix-pipe time each.  Another tile shape = another summation order, so the two agree to rounding, not bit
+    for bit; each matches the oracle to 1e-5.  Row counts around the 16-row tile edges, the one-launch head and the two-launch form
+    (110 / 111), the forced configuration beyond 128 rows (160), the softflow column and the exact path."""
+    robot, hp, lay, sd = custom_model(seed=51, gain=1.5, **kw)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n_max = 200
+    _, poses = reachable_poses(robot, n_max, 103)
+    lat = latents(n_max, lay.dim, 104)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
+    scale = torch.clamp(ref.abs(), min=1.0)
+    try:
+        for n in (1, 2, 15, 16, 17, 31, 33, 64, 100, 127, 128):
+            P, L = poses[:n].to(DEV), lat[:n].to(DEV)
+            kw_n = dict(n=(1 if n == 1 else None), latent=L, clamp_to_joint_limits=False)
+            outs = {}
+            for tiles in (150, 151):
+                for head in (110, 111):
+                    eng.set_gemm_variant(tiles); eng.set_gemm_variant(head)
+                    outs[(tiles, head)] = s.generate_ik_solutions(P, **kw_n).cpu()
+                    err = ((outs[(tiles, head)] - ref[:n]).abs() / scale[:n]).max().item()
+                    assert err <= FLOW_TOL, f"{kw} n={n} tiles {tiles} head {head}: {err:.2e}"
+            assert ((outs[(151, 111)] - outs[(150, 111)]).abs() / scale[:n]).max().item() <= 4e-6
+            assert ((outs[(151, 111)] - outs[(151, 110)]).abs() / scale[:n]).max().item() <= 4e-6
+            assert torch.equal(outs[(151, 111)], s.generate_ik_solutions(P, **kw_n).cpu())  # deterministic
+        eng.set_gemm_variant(151); eng.set_gemm_variant(111)
+        eng.set_gemm_variant(160)  # the 16-row tiles forced for a batch that would not pick them
+        got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
+        assert ((got - ref).abs() / scale).max().item() <= FLOW_TOL
+        eng.set_gemm_variant(100)
+        if lay.dim_cond == 8:  # softflow column
+            cond = torch.cat([poses[:100], torch.full((100, 1), 0.4)], dim=1)
+            got = eng.generate_approx(poses[:100].to(DEV), lat[:100].to(DEV), False, softflow_scale=0.4).cpu()
+            assert (got - fo.run_inference_torch(sd, lay, robot, lat[:100], cond, False)).abs().max().item() <= 10 * FLOW_TOL
+        # exact path at a size whose first round takes the 16-row tiles (pose gather through pose_idx): thresholds hold
+        sol, valid = s.generate_exact_ik_solutions(poses[:60].to(DEV), pos_error_threshold=0.05, rot_error_threshold=0.5)
+        if bool(valid.any()):
+            pe, re = ko.calculate_pose_error(robot, sol[valid].cpu(), poses[:60][valid.cpu()])
+            assert (pe < 0.05 * 1.001).all() and (re < 0.5 * 1.001).all()
+    finally:
+        eng.set_gemm_variant(100); eng.set_gemm_variant(151); eng.set_gemm_variant(111)
+
+
 def test_activation_store_policy_does_not_change_results():
     """ikf_set_gemm_variant 130..134: the hidden activations leave the contractions / the entry kernel with write-back or
     write-through (sc1) stores - a cache policy, so every setting must give identical bits at every tile configuration."""
