@@ -498,6 +498,14 @@ def cell_exact_converged(solver, eng, robot, layout, B, dev, reps, seed, pos_thr
 def run_cells(solver, eng, robot, layout, dev, precision):
     cells = {}
     cells["approx_B512"] = cell_approx(solver, robot, layout, 512, dev, 100, 5)
+    # BASELINE config 1's shape (batch 16) and the reference harnesses' regime (tens of solutions per pose): the only cells where the
+    # HBM roofline binds - one pass streams every weight once (203 MB) whatever the batch
+    for b in (16, 128):
+        c = cell_approx(solver, robot, layout, b, dev, 200, 11 + b)
+        gbps = layout.weight_bytes() / (c["ms_per_call"] * 1e-3) / 1e9
+        c["weight_stream_GBps"] = round(gbps, 1)
+        c["frac_of_hbm_peak_8TBps"] = round(gbps / 8000.0, 4)
+        cells[f"approx_B{b}"] = c
     cells["exact_B4096_worst_case"] = cell_exact(solver, eng, robot, layout, 4096, dev, 5, 6)
     cells["exact_B512_worst_case"] = cell_exact(solver, eng, robot, layout, 512, dev, 10, 7)
     cells["exact_B4096_converged_case"] = cell_exact_converged(solver, eng, robot, layout, 4096, dev, 20, 8)
