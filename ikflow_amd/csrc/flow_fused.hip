@@ -1329,27 +1329,28 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
 #define IK6_LDA(kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
 #define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
   if constexpr (DEEP) {
+    // Every A element of a 16 x 32 tile feeds exactly ONE wave (the eight waves are the eight k slices), so the A rows need no LDS
+    // either: each lane fetches its own fragment - row m0 + lane % 16, four k at 16 kq + 4 (lane / 16) of the k tile - straight from
+    // the activation buffer (64-byte runs per row and wave; the eight waves together read whole 512-byte row segments).  The loop has
+    // no LDS traffic and no barrier.  (The same idea on the 32x32 kernel, whose fragments are 32-byte runs, loses: 0.520 -> 0.533 ms
+    // per call at 256 rows, 1.03 -> 1.17 at 768, where every CU is busy and the narrow loads cost the texture path more than LDS did.)
+    int far = m0 + (lane & 15);
+    far = far < M ? far : M - 1;
+    const unsigned afrag = ((unsigned)far * (unsigned)K + kq * KKW + (lane >> 4) * 4) * 4u;
     floatx4 aall[kDeepTiles], wall[kDeepTiles][2];
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {  // unconditional loads (clamped index past the last tile): the compiler counts them
       const int kc = kt < KT ? kt : KT - 1;
-      aall[kt] = IK6_LDA(kc);
+      aall[kt] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, afrag, __builtin_amdgcn_readfirstlane(kc * (BK * 4)), 0));
       wall[kt][0] = IK6_LDW(woff0, kc);
       wall[kt][1] = IK6_LDW(woff1, kc);
       __builtin_amdgcn_sched_barrier(0);
     }
-    *reinterpret_cast<floatx4*>(smem + ldst) = aall[0];
-    __syncthreads();
-    floatx4 fa = *reinterpret_cast<const floatx4*>(smem + fragA);
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
       if (kt < KT) {  // uniform
-        const int nxt = (kt & 1) ^ 1;
-        if (kt + 1 < kDeepTiles) *reinterpret_cast<floatx4*>(smem + nxt * STAGE + ldst) = aall[kt + 1 < kDeepTiles ? kt + 1 : kt];
-        IKF_MFMA16(fa, wall[kt][0], acc[0])
-        IKF_MFMA16(fa, wall[kt][1], acc[1])
-        __syncthreads();
-        fa = *reinterpret_cast<const floatx4*>(smem + nxt * STAGE + fragA);
+        IKF_MFMA16(aall[kt], wall[kt][0], acc[0])
+        IKF_MFMA16(aall[kt], wall[kt][1], acc[1])
       }
     }
   } else {
