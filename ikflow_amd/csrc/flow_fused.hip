@@ -71,9 +71,9 @@ __device__ __forceinline__ int state_src(const PendingCoupling& pc, int d) {
 // The loads of a pending coupling (state element, bias and the first 32 partial-sum slots of each of this thread's items),
 // split from their use so that a kernel can issue them BEFORE its other prefetches: VMEM returns in order, and a wait in
 // front of the slot sums would otherwise also wait for whatever was queued ahead of them.
-template <int ITEMS>
+template <int ITEMS, int CAP = 32>  // CAP: partial-sum slots held in registers (one memory round trip for up to CAP slots)
 struct PendingLoads {
-  float xv[ITEMS], bias[ITEMS], a[ITEMS][32];
+  float xv[ITEMS], bias[ITEMS], a[ITEMS][CAP];
 };
 
 // SC1: the partial sums were published inside THIS launch by other workgroups (TailSync): agent-scope loads, which bypass
@@ -84,9 +84,9 @@ __device__ __forceinline__ float load_partial(const float* p) {
   else return *p;
 }
 
-template <int NT, int R, bool SC1 = false>
+template <int NT, int R, bool SC1 = false, int CAP = 32>
 __device__ __forceinline__ void pending_issue_loads(const PendingCoupling& pc, const float* __restrict__ x_src, int D, int L1,
-                                                    int m0, int M, int t, PendingLoads<(R * ROWBUF + NT - 1) / NT>& pl) {
+                                                    int m0, int M, int t, PendingLoads<(R * ROWBUF + NT - 1) / NT, CAP>& pl) {
   constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
   const int nl = (pc.which == 1) ? D - L1 : L1;
 #pragma unroll
@@ -99,14 +99,14 @@ __device__ __forceinline__ void pending_issue_loads(const PendingCoupling& pc, c
     const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + d;  // P rows are padded to the tile: no clamp needed
     pl.bias[it] = has_sum ? pc.b_last[d] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 32; ++q) pl.a[it][q] = (has_sum && q < pc.slots) ? load_partial<SC1>(p + (size_t)q * pc.slot_stride) : 0.f;
+    for (int q = 0; q < CAP; ++q) pl.a[it][q] = (has_sum && q < pc.slots) ? load_partial<SC1>(p + (size_t)q * pc.slot_stride) : 0.f;
   }
 }
 
 // Phase A: one thread per (row, subnet output o) sums that output's slots in fixed order (bias, slot 0, slot 1, ..) and parks
 // the sum in LDS.  Phase B: one thread per (row, state element) applies the coupling (see above).  Ends with a barrier.
-template <int NT, int R>
-__device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const PendingLoads<(R * ROWBUF + NT - 1) / NT>& pl,
+template <int NT, int R, int CAP = 32>
+__device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, const PendingLoads<(R * ROWBUF + NT - 1) / NT, CAP>& pl,
                                                     int D, int L1, float clamp, int m0, float* cat, float* sums, int t) {
   constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
   const int L2 = D - L1;
@@ -120,10 +120,10 @@ __device__ __forceinline__ void finish_pending_rows(const PendingCoupling& pc, c
       if (idx >= R * ROWBUF || o >= 2 * nl) continue;
       float sv = pl.bias[it];
 #pragma unroll
-      for (int q = 0; q < 32; ++q) sv += pl.a[it][q];
-      if (pc.slots > 32) {  // wider than any released model's tiles: the remaining slots in chunks of 32
+      for (int q = 0; q < CAP; ++q) sv += pl.a[it][q];
+      if (pc.slots > CAP) {  // more slots than the registers hold: the remaining ones in chunks of 32 (another round trip each)
         const float* p = pc.P + (size_t)(m0 + r) * IKF_PSTRIDE + o;
-        for (int s0 = 32; s0 < pc.slots; s0 += 32) {
+        for (int s0 = CAP; s0 < pc.slots; s0 += 32) {
           float a[32];
 #pragma unroll
           for (int q = 0; q < 32; ++q) a[q] = (s0 + q < pc.slots) ? p[(size_t)(s0 + q) * pc.slot_stride] : 0.f;
@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e
 // chain): results agree with the other tile shapes to rounding, like every change of tile shape.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int S16_ROWS = 16;
-constexpr size_t skinny16_tail_lds() { return sizeof(float) * ((size_t)KKS * 2 * 4 * 64 + (size_t)(S16_ROWS + 16) * (32 + 4)); }
+constexpr size_t skinny16_tail_lds() { return sizeof(float) * ((size_t)KKS * 2 * 4 * 64 + (size_t)(S16_ROWS + 16) * (32 + 4)); }  // (two column blocks: the larger case)
 constexpr size_t skinny16_lds() {
   return skinny16_tail_lds() > sizeof(float) * 2 * S16_ROWS * (KBK + 4) ? skinny16_tail_lds() : sizeof(float) * 2 * S16_ROWS * (KBK + 4);
 }
@@ -1246,33 +1246,39 @@ __device__ __forceinline__ unsigned wfrag16_off(int kq, int lane, int cb) {
 
 // tail of the 16-row kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.  Call after a barrier
 // that ends every LDS read of the loop.  acc[cb][v] = tile[row = 4 * (lane / 16) + v][col = 16 cb + lane % 16] over this wave's k slice.
-template <bool EPI_RED>
-__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[2], float* smem, int m0, int n0, int t,
+// NCB = 16-column blocks per tile: 2 (16 x 32 tiles, <= 128 rows) or 1 (16 x 16 tiles, <= 64 rows: twice the workgroups again).
+template <bool EPI_RED, int NCB>
+__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[NCB], float* smem, int m0, int n0, int t,
                                               int lane, int kq) {
-  constexpr int BN = 32, LDT = BN + 4, NT = KKS * 64;
+  constexpr int BN = 16 * NCB, LDT = BN + 4, NT = KKS * 64;
   const int N = g.N;
-  float* red = smem;  // [KKS][2][4][64]
+  float* red = smem;  // [KKS][NCB][4][64]
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) red[((kq * 2 + cb) * 4 + v) * 64 + lane] = acc[cb][v];
+    for (int v = 0; v < 4; ++v) red[((kq * NCB + cb) * 4 + v) * 64 + lane] = acc[cb][v];
   __syncthreads();
-  // wave kq finishes accumulator register (cb = kq / 4, v = kq % 4) of every lane: the k slices in fixed order 0, 1, ..
+  // wave kq < 4 NCB finishes accumulator register (cb = kq / 4, v = kq % 4) of every lane: the k slices in fixed order 0, 1, ..
+  const bool fin_wave = kq < 4 * NCB;
   const int cb = kq >> 2, v = kq & 3;
   float fin = 0.f;
-#pragma unroll
-  for (int q = 0; q < KKS; ++q) fin += red[((q * 2 + cb) * 4 + v) * 64 + lane];
   const int row = 4 * (lane >> 4) + v, col = cb * 16 + (lane & 15);
-  fin += g.bias[n0 + col];
-  fin = fin > 0.f ? fin : fin * g.slope;
+  if (fin_wave) {
+#pragma unroll
+    for (int q = 0; q < KKS; ++q) fin += red[((q * NCB + cb) * 4 + v) * 64 + lane];
+    fin += g.bias[n0 + col];
+    fin = fin > 0.f ? fin : fin * g.slope;
+  }
   if constexpr (!EPI_RED) {
-    float* dst = g.C + (size_t)(m0 + row) * N + n0 + col;  // row-padded buffer: unpredicated
-    if (g.wt_stores) __hip_atomic_store(dst, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *dst = fin;
+    if (fin_wave) {
+      float* dst = g.C + (size_t)(m0 + row) * N + n0 + col;  // row-padded buffer: unpredicated
+      if (g.wt_stores) __hip_atomic_store(dst, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *dst = fin;
+    }
   } else {
-    float* T = smem + KKS * 2 * 4 * 64;  // [16][LDT], behind red[] (other waves may still be summing)
-    float* Wl = T + S16_ROWS * LDT;      // [16][LDT]: w_last rows (zero beyond n_out), this tile's 32 columns
-    T[row * LDT + col] = fin;
+    float* T = smem + KKS * NCB * 4 * 64;  // [16][LDT], behind red[] (other waves may still be summing)
+    float* Wl = T + S16_ROWS * LDT;        // [16][LDT]: w_last rows (zero beyond n_out), this tile's columns
+    if (fin_wave) T[row * LDT + col] = fin;
     for (int idx = t; idx < 16 * (BN / 4); idx += NT) {
       const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
       floatx4 w = {0.f, 0.f, 0.f, 0.f};
@@ -1280,11 +1286,11 @@ __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floa
       *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = w;
     }
     __syncthreads();
-    if (kq == 0) {  // one wave: P[row][o] = sum over the tile's 32 columns of h[row][col] * w_last[o][col], one MFMA chain
+    if (kq == 0) {  // one wave: P[row][o] = sum over the tile's columns of h[row][col] * w_last[o][col], one MFMA chain
       floatx4 pacc = {0.f, 0.f, 0.f, 0.f};
       const int gq = lane >> 4;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NCB; ++h) {
         const floatx4 a4 = *reinterpret_cast<const floatx4*>(T + (lane & 15) * LDT + 16 * h + 4 * gq);
         const floatx4 b4 = *reinterpret_cast<const floatx4*>(Wl + (lane & 15) * LDT + 16 * h + 4 * gq);
         IKF_MFMA16(a4, b4, pacc)
@@ -1302,9 +1308,9 @@ __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floa
 // requested up front, tile by tile (sched_barrier keeps that order: tile 0 must not queue behind the rest).  A k tile is only 0.2 us of
 // matrix-pipe time per SIMD here, so two tiles of lead (0.4 us) no longer cover a memory round trip (1 - 2 us).
 constexpr int kDeepTiles = 8;
-template <bool EPI_RED, bool DEEP>
+template <bool EPI_RED, bool DEEP, int NCB = 2>
 __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g) {
-  constexpr int BM = S16_ROWS, BN = 32, BK = KBK, NT = KKS * 64, LDK = BK + 4, KQ4 = BK / 4, STAGE = BM * LDK;
+  constexpr int BM = S16_ROWS, BN = 16 * NCB, BK = KBK, NT = KKS * 64, LDK = BK + 4, KQ4 = BK / 4, STAGE = BM * LDK;
   static_assert(BM * KQ4 == NT, "one float4 of the A tile per thread per stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int M = g.M, N = g.N, K = g.K;
@@ -1313,7 +1319,9 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, kq = __builtin_amdgcn_readfirstlane(t >> 6);
-  floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  floatx4 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
   const int arow = t / KQ4, ac4 = t - arow * KQ4;
   int gr = m0 + arow;
   gr = gr < M ? gr : M - 1;
@@ -1323,8 +1331,10 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   const int KT = K / BK;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
-  const unsigned wtile0 = (unsigned)tn * KT;
-  const unsigned woff0 = wfrag16_off(kq, lane, 0), woff1 = wfrag16_off(kq, lane, 1);
+  const unsigned wtile0 = (unsigned)(n0 >> 5) * KT;  // the 32-column tile of the fragment-major image this tile lies in
+  unsigned woffs[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) woffs[cb] = wfrag16_off(kq, lane, ((n0 >> 4) & 1) + cb);
   const int fragA = (lane & 15) * LDK + kq * KKW + (lane >> 4) * 4;
 #define IK6_LDA(kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
 #define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
@@ -1337,29 +1347,32 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
     int far = m0 + (lane & 15);
     far = far < M ? far : M - 1;
     const unsigned afrag = ((unsigned)far * (unsigned)K + kq * KKW + (lane >> 4) * 4) * 4u;
-    floatx4 aall[kDeepTiles], wall[kDeepTiles][2];
+    floatx4 aall[kDeepTiles], wall[kDeepTiles][NCB];
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {  // unconditional loads (clamped index past the last tile): the compiler counts them
       const int kc = kt < KT ? kt : KT - 1;
       aall[kt] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, afrag, __builtin_amdgcn_readfirstlane(kc * (BK * 4)), 0));
-      wall[kt][0] = IK6_LDW(woff0, kc);
-      wall[kt][1] = IK6_LDW(woff1, kc);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) wall[kt][cb] = IK6_LDW(woffs[cb], kc);
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
       if (kt < KT) {  // uniform
-        IKF_MFMA16(aall[kt], wall[kt][0], acc[0])
-        IKF_MFMA16(aall[kt], wall[kt][1], acc[1])
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(aall[kt], wall[kt][cb], acc[cb])
       }
     }
   } else {
     floatx4 rg = IK6_LDA(0);
-    floatx4 wc0 = IK6_LDW(woff0, 0), wc1 = IK6_LDW(woff1, 0);
+    floatx4 wc[NCB], wn[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) wc[cb] = IK6_LDW(woffs[cb], 0);
     *reinterpret_cast<floatx4*>(smem + ldst) = rg;
     const int k1 = KT > 1 ? 1 : 0;
     rg = IK6_LDA(k1);
-    floatx4 wn0 = IK6_LDW(woff0, k1), wn1 = IK6_LDW(woff1, k1);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) wn[cb] = IK6_LDW(woffs[cb], k1);
     __syncthreads();
     floatx4 fa = *reinterpret_cast<const floatx4*>(smem + fragA);
     // iteration kt: A tile kt+1 (in rg) -> the other stage, tile kt+2 requested; MFMAs of tile kt; barrier; fragment of tile kt+1.
@@ -1369,12 +1382,12 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
       const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
       *reinterpret_cast<floatx4*>(smem + nxt * STAGE + ldst) = rg;
       rg = IK6_LDA(k2);
-      IKF_MFMA16(fa, wc0, acc[0])
-      IKF_MFMA16(fa, wc1, acc[1])
-      wc0 = wn0;
-      wc1 = wn1;
-      wn0 = IK6_LDW(woff0, k2);
-      wn1 = IK6_LDW(woff1, k2);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        IKF_MFMA16(fa, wc[cb], acc[cb])
+        wc[cb] = wn[cb];
+        wn[cb] = IK6_LDW(woffs[cb], k2);
+      }
       __syncthreads();
       fa = *reinterpret_cast<const floatx4*>(smem + nxt * STAGE + fragA);
     }
@@ -1382,14 +1395,15 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
 #undef IK6_LDA
 #undef IK6_LDW
   __syncthreads();  // all fragment reads done before the stage area is reused
-  skinny16_tail<EPI_RED>(g, acc, smem, m0, n0, t, lane, kq);
+  skinny16_tail<EPI_RED, NCB>(g, acc, smem, m0, n0, t, lane, kq);
 }
 
 // one-launch subnet head, 16 x 32 tiles: pending coupling of the tile's 16 rows, the whole first Linear + LeakyReLU of those rows
 // on the matrix pipe into a resident LDS tile, barrier-free K loop (see k_entry_gemm_skinny).
-template <bool EPI_RED, bool DEEP>
+template <bool EPI_RED, bool DEEP, int NCB = 2>
 __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
-  constexpr int BN = 32, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS;
+  constexpr int BN = 16 * NCB, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS;
+  constexpr int CAP = NCB == 1 ? 64 : 32;  // partial-sum slots read in one round trip (16-column tiles make twice as many slots)
   constexpr int BPW_MAX = 8;  // first-Linear 16-column blocks per wave at K = 1024
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = g.K, N = g.N;
@@ -1407,30 +1421,33 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   const int M = e.M, D = e.D;
   const int gq = lane >> 4, cl = lane & 15;
 
-  PendingLoads<(R * ROWBUF + NT - 1) / NT> pl;
-  pending_issue_loads<NT, R>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);  // the critical path's loads go first
+  PendingLoads<(R * ROWBUF + NT - 1) / NT, CAP> pl;
+  pending_issue_loads<NT, R, false, CAP>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);  // the critical path's loads go first
 
   constexpr int WTILE = KKS * KKG * 256;
   const int KT = K / BK;
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
-  const unsigned wtile0 = (unsigned)tn * KT;
-  const unsigned woff0 = wfrag16_off(kq, lane, 0), woff1 = wfrag16_off(kq, lane, 1);
+  const unsigned wtile0 = (unsigned)(n0 >> 5) * KT;
+  unsigned woffs[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) woffs[cb] = wfrag16_off(kq, lane, ((n0 >> 4) & 1) + cb);
 #define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
-  floatx4 wc0, wc1, wn0, wn1;
-  floatx4 wall[DEEP ? kDeepTiles : 1][2];
+  floatx4 wc[NCB], wn[NCB];
+  floatx4 wall[DEEP ? kDeepTiles : 1][NCB];
   if constexpr (DEEP) {  // the whole W-fragment stream now: it has the pending and first-Linear phases to arrive in
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
       const int kc = kt < KT ? kt : KT - 1;
-      wall[kt][0] = IK6_LDW(woff0, kc);
-      wall[kt][1] = IK6_LDW(woff1, kc);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) wall[kt][cb] = IK6_LDW(woffs[cb], kc);
     }
   } else {
-    wc0 = IK6_LDW(woff0, 0);
-    wc1 = IK6_LDW(woff1, 0);
     const int k1 = KT > 1 ? 1 : 0;
-    wn0 = IK6_LDW(woff0, k1);
-    wn1 = IK6_LDW(woff1, k1);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      wc[cb] = IK6_LDW(woffs[cb], 0);
+      wn[cb] = IK6_LDW(woffs[cb], k1);
+    }
   }
 
   // first-Linear operands of this wave's 16-column blocks: MFMA "A" = W1^T (i = column of the block), "B" = the input rows
@@ -1461,7 +1478,7 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
     pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
   }
-  finish_pending_rows<NT, R>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
+  finish_pending_rows<NT, R, CAP>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
   if (t < R * ROWBUF) {
     if (tn == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
     U[ur * EG_ULD + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;  // 0 beyond n_in
@@ -1488,32 +1505,34 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     }
   }
   __syncthreads();
-  floatx4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  floatx4 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
   const float* fragA = A_full + (size_t)cl * LDKF + kq * KKW + gq * 4;
   if constexpr (DEEP) {
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
       if (kt < KT) {  // uniform; barrier-free: A fragments from the resident tile
         const floatx4 fa = *reinterpret_cast<const floatx4*>(fragA + kt * BK);
-        IKF_MFMA16(fa, wall[kt][0], acc[0])
-        IKF_MFMA16(fa, wall[kt][1], acc[1])
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(fa, wall[kt][cb], acc[cb])
       }
     }
   } else {
     for (int kt = 0; kt < KT; ++kt) {  // barrier-free: A fragments from the resident tile, W fragments two tiles ahead
       const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
       const floatx4 fa = *reinterpret_cast<const floatx4*>(fragA + kt * BK);
-      IKF_MFMA16(fa, wc0, acc[0])
-      IKF_MFMA16(fa, wc1, acc[1])
-      wc0 = wn0;
-      wc1 = wn1;
-      wn0 = IK6_LDW(woff0, k2);
-      wn1 = IK6_LDW(woff1, k2);
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        IKF_MFMA16(fa, wc[cb], acc[cb])
+        wc[cb] = wn[cb];
+        wn[cb] = IK6_LDW(woffs[cb], k2);
+      }
     }
   }
 #undef IK6_LDW
   __syncthreads();  // every wave is done with A_full before the tail reuses the memory
-  skinny16_tail<EPI_RED>(g, acc, smem, m0, n0, t, lane, kq);
+  skinny16_tail<EPI_RED, NCB>(g, acc, smem, m0, n0, t, lane, kq);
 }
 #undef IKF_MFMA16
 
@@ -1576,32 +1595,32 @@ static hipError_t launch_entry_gemm_t(const EntryArgs& e, const FusedGemmArgs& a
 }
 
 int g_deep16 = 1;  // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole stream
-template <bool EPI_RED, bool DEEP>
+template <bool EPI_RED, bool DEEP, int NCB>
 static hipError_t launch_skinny16(const FusedGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = skinny16_lds();
-  auto kern = k_flow_gemm_skinny16<EPI_RED, DEEP>;
+  auto kern = k_flow_gemm_skinny16<EPI_RED, DEEP, NCB>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
-  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / 32);
+  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / (16 * NCB));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, a);
   return hipGetLastError();
 }
-template <bool EPI_RED, bool DEEP>
+template <bool EPI_RED, bool DEEP, int NCB>
 static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a, int n_in, hipStream_t s) {
   size_t smem = entry_gemm16_lds(a.K);
   if (smem < skinny16_tail_lds()) smem = skinny16_tail_lds();
-  auto kern = k_entry_gemm_skinny16<EPI_RED, DEEP>;
+  auto kern = k_entry_gemm_skinny16<EPI_RED, DEEP, NCB>;
   static bool lds_ok[64] = {};
   if (hipError_t err = ensure_dynamic_lds(kern, (size_t)160 * 1024, lds_ok); err != hipSuccess) return err;
-  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / 32);
+  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / (16 * NCB));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, e, a, n_in);
   return hipGetLastError();
 }
 
 // true when the first hidden contraction of a subnet can run as k_entry_gemm_skinny for this batch
 bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out) {
-  if (cfg == 9) {  // kSkinny16Cfg: 16 x 32 tiles
-    const long long tiles = ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32);
+  if (cfg == 9 || cfg == 10) {  // kSkinny16Cfg: 16 x 32 tiles; kSkinny16x16Cfg: 16 x 16 tiles
+    const long long tiles = ((rows + S16_ROWS - 1) / S16_ROWS) * (width / (cfg == 9 ? 32 : 16));
     return tiles <= 512 && width <= 2048 && width % (2 * KBK) == 0 && (width / 16) % KKS == 0 && (width / 16) / KKS <= 8 &&
            D <= ROWBUF && n_out <= ROWBUF;  // (its 69 KB of LDS at width 1024 lets two workgroups share a CU)
   }
@@ -1619,8 +1638,13 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
     return hipErrorInvalidValue;
   if (cfg == 9) {
     if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
-      return epi_red ? launch_entry_gemm16<true, true>(e, a, n_in, s) : launch_entry_gemm16<false, true>(e, a, n_in, s);
-    return epi_red ? launch_entry_gemm16<true, false>(e, a, n_in, s) : launch_entry_gemm16<false, false>(e, a, n_in, s);
+      return epi_red ? launch_entry_gemm16<true, true, 2>(e, a, n_in, s) : launch_entry_gemm16<false, true, 2>(e, a, n_in, s);
+    return epi_red ? launch_entry_gemm16<true, false, 2>(e, a, n_in, s) : launch_entry_gemm16<false, false, 2>(e, a, n_in, s);
+  }
+  if (cfg == 10) {
+    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
+      return epi_red ? launch_entry_gemm16<true, true, 1>(e, a, n_in, s) : launch_entry_gemm16<false, true, 1>(e, a, n_in, s);
+    return epi_red ? launch_entry_gemm16<true, false, 1>(e, a, n_in, s) : launch_entry_gemm16<false, false, 1>(e, a, n_in, s);
   }
   if (cfg == 4) return epi_red ? launch_entry_gemm_t<true, 2>(e, a, n_in, s) : launch_entry_gemm_t<false, 2>(e, a, n_in, s);
   return epi_red ? launch_entry_gemm_t<true, 1>(e, a, n_in, s) : launch_entry_gemm_t<false, 1>(e, a, n_in, s);
@@ -1629,13 +1653,17 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kSkinnyCfg = 4;    // k_flow_gemm_skinny<.., 2>: 32x64 tiles
 constexpr int kSkinny32Cfg = 6;  // k_flow_gemm_skinny<.., 1>: 32x32 tiles (5 is the 4-wave probe of the large tile)
-constexpr int kSkinny16Cfg = 9;  // k_flow_gemm_skinny16: 16x32 tiles on v_mfma_f32_16x16x4_f32 (<= 128 rows)
+constexpr int kSkinny16Cfg = 9;     // k_flow_gemm_skinny16<.., 2>: 16x32 tiles on v_mfma_f32_16x16x4_f32 (<= 128 rows)
+constexpr int kSkinny16x16Cfg = 10;  // k_flow_gemm_skinny16<.., 1>: 16x16 tiles (<= 64 rows)
+int g_skinny16x16 = 1;               // probes / tests: 0 = batches of <= 64 rows keep the 16x32 tiles
 int g_skinny16 = 1;              // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles
 int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_skinny32_cfg() { return kSkinny32Cfg; }
 int fused_skinny16_cfg() { return kSkinny16Cfg; }
+int fused_skinny16x16_cfg() { return kSkinny16x16Cfg; }
 int fused_pick_cfg(long long rows, int width) {
   if (width % KBN == 0 && width % (2 * KBK) == 0) {
+    if (rows <= 64 && g_skinny16 != 0 && g_skinny16x16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 16) <= 256) return kSkinny16x16Cfg;
     if (rows <= 128 && g_skinny16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32) <= 256) return kSkinny16Cfg;
     if (rows <= 256) return kSkinny32Cfg;
     if (rows <= 512) return kSkinnyCfg;
@@ -1660,8 +1688,10 @@ int fused_pick_cfg(long long rows, int width) {
   return -1;
 }
 // partial-sum slots of the last Linear: one per 64 columns, except the 32-column small-batch tiles (half slots)
-int fused_slots(int cfg, int width) { return (cfg == kSkinny32Cfg || cfg == kSkinny16Cfg) ? width / 32 : width / 64; }
-int fused_max_slots(int width) { return width / 32; }
+int fused_slots(int cfg, int width) {
+  return cfg == kSkinny16x16Cfg ? width / 16 : (cfg == kSkinny32Cfg || cfg == kSkinny16Cfg) ? width / 32 : width / 64;
+}
+int fused_max_slots(int width) { return width / 16; }
 const char* fused_kernel_name() { return "k_flow_gemm"; }
 
 template <bool EPI_RED, int CFG>
@@ -1713,10 +1743,15 @@ hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArg
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
-  if (cfg == kSkinny16Cfg) {
+  if (cfg == kSkinny16Cfg || cfg == kSkinny16x16Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
-    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK) return epi_red ? launch_skinny16<true, true>(a, s) : launch_skinny16<false, true>(a, s);
-    return epi_red ? launch_skinny16<true, false>(a, s) : launch_skinny16<false, false>(a, s);
+    const bool deep = g_deep16 != 0 && a.K <= kDeepTiles * KBK;
+    if (cfg == kSkinny16Cfg) {
+      if (deep) return epi_red ? launch_skinny16<true, true, 2>(a, s) : launch_skinny16<false, true, 2>(a, s);
+      return epi_red ? launch_skinny16<true, false, 2>(a, s) : launch_skinny16<false, false, 2>(a, s);
+    }
+    if (deep) return epi_red ? launch_skinny16<true, true, 1>(a, s) : launch_skinny16<false, true, 1>(a, s);
+    return epi_red ? launch_skinny16<true, false, 1>(a, s) : launch_skinny16<false, false, 1>(a, s);
   }
   if (cfg == kSkinnyCfg || cfg == kSkinny32Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;

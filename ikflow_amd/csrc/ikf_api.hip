@@ -639,9 +639,13 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_tail = variant - 120;
     return IKF_OK;
   }
-  if (variant == 160) {  // fused pipeline with the 16x32 small-batch tiles forced (tile config 9)
+  if (variant == 160 || variant == 161) {  // fused pipeline with the 16x32 / 16x16 small-batch tiles forced (tile config 9 / 10)
     m->gemm_variant = 100;
-    m->tile_cfg = 9;
+    m->tile_cfg = variant - 151;
+    return IKF_OK;
+  }
+  if (variant == 158 || variant == 159) {  // <= 64 rows on 16x16 tiles: off / on (process-wide probe / test switch)
+    g_skinny16x16 = variant - 158;
     return IKF_OK;
   }
   if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
@@ -699,7 +703,9 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const long long rows_pad = m->chunk_rows;
   const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width);
   // f16x3 mode: its own tile choice; the partial-sum slots follow the kernel that writes them
-  const bool split = (m->precision == 1) && m->split_arena != nullptr;
+  // (f16x3 mode, batches that pick the 16-row f32 tiles - <= 128 rows: the exact-f32 kernels are the faster ones there since round 3,
+  // 0.43 against 0.46 ms per call, so the mode steps aside; a forced tile configuration keeps the split kernels)
+  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && (cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg()));
   int scfg = -1;
   if (split) {
     scfg = (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width);
@@ -747,7 +753,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     // one launch takes as long as the two it replaces (18.4 us against 5.5 + 13.0), so those keep the two-launch form
     // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
     const bool one_launch = !tail && !split &&
-                            (m->fuse_entry == 2 || (m->fuse_entry == 1 && (cfg == fused_skinny32_cfg() || cfg == fused_skinny16_cfg()))) &&
+                            (m->fuse_entry == 2 || (m->fuse_entry == 1 && (cfg == fused_skinny32_cfg() || cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg()))) &&
                             entry_gemm_ok(cfg, nr, d.width, d.D, pend.P ? pend.n_out : 0) &&
                             frag_image(m, 2 * b + which - 1, 0) != nullptr;
     if (!one_launch && !entry_done) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));

@@ -1371,8 +1371,8 @@ def test_in_launch_entry_phase_equals_entry_launches(kw):
     dict(nb_nodes=2, dim=7, n_hidden=3, width=512, softflow=False, sigmoid=True),
 ])
 def test_sixteen_row_tiles_for_small_batches(kw):
-    """<= 128 rows run on 16 x 32 tiles (v_mfma_f32_16x16x4_f32; ikf_set_gemm_variant 151, the default) instead of 32 x 32 (150): twice
-    the workgroups, half the matrix-pipe time each.  Another tile shape = another summation order, so the two agree to rounding, not bit
+    """<= 128 rows run on 16 x 32 tiles and <= 64 rows on 16 x 16 tiles (v_mfma_f32_16x16x4_f32; ikf_set_gemm_variant 151 / 159, the
+    defaults) instead of 32 x 32 (150): twice / four times the workgroups, a half / a quarter of the matrix-pipe time each.  Another tile shape = another summation order, so the two agree to rounding, not bit
     for bit; each matches the oracle to 1e-5.  Row counts around the 16-row tile edges, the one-launch head and the two-launch form
     (110 / 111), the forced configuration beyond 128 rows (160), the softflow column and the exact path."""
     robot, hp, lay, sd = custom_model(seed=51, gain=1.5, **kw)
@@ -1388,19 +1388,22 @@ def test_sixteen_row_tiles_for_small_batches(kw):
             P, L = poses[:n].to(DEV), lat[:n].to(DEV)
             kw_n = dict(n=(1 if n == 1 else None), latent=L, clamp_to_joint_limits=False)
             outs = {}
-            for tiles in (150, 151):
+            for tiles in (150, 151, 158):  # 32x32 tiles / the default (16x16 up to 64 rows, 16x32 up to 128) / 16x32 only
                 for head in (110, 111):
+                    eng.set_gemm_variant(151); eng.set_gemm_variant(159)
                     eng.set_gemm_variant(tiles); eng.set_gemm_variant(head)
                     outs[(tiles, head)] = s.generate_ik_solutions(P, **kw_n).cpu()
                     err = ((outs[(tiles, head)] - ref[:n]).abs() / scale[:n]).max().item()
                     assert err <= FLOW_TOL, f"{kw} n={n} tiles {tiles} head {head}: {err:.2e}"
-            assert ((outs[(151, 111)] - outs[(150, 111)]).abs() / scale[:n]).max().item() <= 4e-6
-            assert ((outs[(151, 111)] - outs[(151, 110)]).abs() / scale[:n]).max().item() <= 4e-6
+            for other in ((150, 111), (151, 110), (158, 111), (158, 110)):
+                assert ((outs[(151, 111)] - outs[other]).abs() / scale[:n]).max().item() <= 4e-6, other
+            eng.set_gemm_variant(151); eng.set_gemm_variant(159); eng.set_gemm_variant(111)
             assert torch.equal(outs[(151, 111)], s.generate_ik_solutions(P, **kw_n).cpu())  # deterministic
         eng.set_gemm_variant(151); eng.set_gemm_variant(111)
-        eng.set_gemm_variant(160)  # the 16-row tiles forced for a batch that would not pick them
-        got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
-        assert ((got - ref).abs() / scale).max().item() <= FLOW_TOL
+        for forced in (160, 161):  # the 16x32 / 16x16 tiles forced for a batch that would not pick them
+            eng.set_gemm_variant(forced)
+            got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
+            assert ((got - ref).abs() / scale).max().item() <= FLOW_TOL, forced
         eng.set_gemm_variant(100)
         if lay.dim_cond == 8:  # softflow column
             cond = torch.cat([poses[:100], torch.full((100, 1), 0.4)], dim=1)
@@ -1412,7 +1415,7 @@ def test_sixteen_row_tiles_for_small_batches(kw):
             pe, re = ko.calculate_pose_error(robot, sol[valid].cpu(), poses[:60][valid.cpu()])
             assert (pe < 0.05 * 1.001).all() and (re < 0.5 * 1.001).all()
     finally:
-        eng.set_gemm_variant(100); eng.set_gemm_variant(151); eng.set_gemm_variant(111)
+        eng.set_gemm_variant(100); eng.set_gemm_variant(151); eng.set_gemm_variant(159); eng.set_gemm_variant(111)
 
 
 def test_activation_store_policy_does_not_change_results():
