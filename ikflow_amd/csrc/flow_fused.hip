@@ -1228,9 +1228,7 @@ constexpr size_t skinny16_tail_lds() { return sizeof(float) * ((size_t)KKS * 2 *
 constexpr size_t skinny16_lds() {
   return skinny16_tail_lds() > sizeof(float) * 2 * S16_ROWS * (KBK + 4) ? skinny16_tail_lds() : sizeof(float) * 2 * S16_ROWS * (KBK + 4);
 }
-constexpr size_t entry_gemm16_lds(int K) {
-  return sizeof(float) * ((size_t)S16_ROWS * (K + 4) + 2 * S16_ROWS * ROWBUF + S16_ROWS * EG_ULD);
-}
+constexpr size_t entry_gemm16_lds() { return sizeof(float) * ((size_t)2 * S16_ROWS * ROWBUF + S16_ROWS * EG_ULD); }
 #define IKF_MFMA16(FA, FB, ACC)                                                      \
   {                                                                                  \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.x, FB.x, ACC, 0, 0, 0);            \
@@ -1398,8 +1396,11 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   skinny16_tail<EPI_RED, NCB>(g, acc, smem, m0, n0, t, lane, kq);
 }
 
-// one-launch subnet head, 16 x 32 tiles: pending coupling of the tile's 16 rows, the whole first Linear + LeakyReLU of those rows
-// on the matrix pipe into a resident LDS tile, barrier-free K loop (see k_entry_gemm_skinny).
+// one-launch subnet head, 16-row tiles: pending coupling of the tile's 16 rows, the whole first Linear + LeakyReLU of those rows on
+// the matrix pipe, K loop.  The hidden activation h1 NEVER LEAVES THE REGISTERS: wave kq evaluates exactly the 16-column blocks it
+// will contract - block 8 kt + kq is k slice kq of k tile kt - and the transposed first-Linear product leaves lane l with
+// h1[row = l % 16][16 b + 4 (l / 16) + v] in accumulator register v, which is precisely the A fragment (four consecutive k at offset
+// 4 (l / 16) of the slice) the K loop's MFMAs want.  No LDS tile, no barrier between the first Linear and the loop.
 template <bool EPI_RED, bool DEEP, int NCB = 2>
 __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
   constexpr int BN = 16 * NCB, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS;
@@ -1407,11 +1408,9 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   constexpr int BPW_MAX = 8;  // first-Linear 16-column blocks per wave at K = 1024
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = g.K, N = g.N;
-  const int LDKF = K + 4;
-  float* A_full = smem;                    // [R][K + 4]; reused by the tail after the loop
-  float* cat = smem + (size_t)R * LDKF;    // [R][ROWBUF]
+  float* cat = smem;               // [R][ROWBUF]   (all three are dead before the tail reuses the memory)
   float* sums = cat + R * ROWBUF;
-  float* U = sums + R * ROWBUF;            // [R][EG_ULD]
+  float* U = sums + R * ROWBUF;    // [R][EG_ULD]
   const int tiles_n = N / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * R, n0 = tn * BN;
@@ -1452,12 +1451,12 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
 
   // first-Linear operands of this wave's 16-column blocks: MFMA "A" = W1^T (i = column of the block), "B" = the input rows
   // (j = row), so that a lane's four accumulator registers are four CONSECUTIVE columns of one row
-  const int bpw = (K / 16) / NW;  // launcher: divides, <= BPW_MAX
+  const int bpw = (K / 16) / NW;  // = K / 128 = the k tiles (launcher: <= BPW_MAX); block i of this wave is k slice kq of k tile i
   float wb[BPW_MAX][4];
   floatx4 bias4[BPW_MAX];
 #pragma unroll
   for (int i = 0; i < BPW_MAX; ++i) {
-    const int cb = i < bpw ? wave * bpw + i : 0;
+    const int cb = i < bpw ? i * NW + wave : 0;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const int k = 4 * s4 + gq;
@@ -1484,14 +1483,15 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     U[ur * EG_ULD + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;  // 0 beyond n_in
   }
   __syncthreads();
+  floatx4 afrag[BPW_MAX];  // afrag[kt][v] = h1[row = lane % 16][k = 128 kt + 16 kq + 4 (lane / 16) + v]: the K loop's A fragments
   {
     float ua[4];  // "B" fragment of step s: U[row = lane % 16][k = 4 s + lane / 16]
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) ua[s4] = U[cl * EG_ULD + 4 * s4 + gq];
 #pragma unroll
     for (int i = 0; i < BPW_MAX; ++i) {
+      floatx4 a1 = bias4[i];
       if (i < bpw) {
-        floatx4 a1 = bias4[i];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
           if (4 * s4 < n_in) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s4], ua[s4], a1, 0, 0, 0);  // k past n_in: 0 * 0
@@ -1499,39 +1499,39 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
         a1.y = a1.y > 0.f ? a1.y : a1.y * e.slope;
         a1.z = a1.z > 0.f ? a1.z : a1.z * e.slope;
         a1.w = a1.w > 0.f ? a1.w : a1.w * e.slope;
-        // a1[v] = h1[row = lane % 16][column = 16 (wave bpw + i) + 4 (lane / 16) + v]
-        *reinterpret_cast<floatx4*>(A_full + (size_t)cl * LDKF + (wave * bpw + i) * 16 + 4 * gq) = a1;
       }
+      afrag[i] = a1;
     }
   }
-  __syncthreads();
   floatx4 acc[NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-  const float* fragA = A_full + (size_t)cl * LDKF + kq * KKW + gq * 4;
+  static_assert(BPW_MAX == kDeepTiles, "one first-Linear block per k tile");
   if constexpr (DEEP) {
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
-      if (kt < KT) {  // uniform; barrier-free: A fragments from the resident tile
-        const floatx4 fa = *reinterpret_cast<const floatx4*>(fragA + kt * BK);
+      if (kt < KT) {  // uniform; no LDS, no barrier
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(fa, wall[kt][cb], acc[cb])
+        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(afrag[kt], wall[kt][cb], acc[cb])
       }
     }
   } else {
-    for (int kt = 0; kt < KT; ++kt) {  // barrier-free: A fragments from the resident tile, W fragments two tiles ahead
+#pragma unroll
+    for (int kt = 0; kt < kDeepTiles; ++kt) {  // W fragments two tiles ahead (unconditional loads, clamped index)
       const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
-      const floatx4 fa = *reinterpret_cast<const floatx4*>(fragA + kt * BK);
+      if (kt < KT) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(afrag[kt], wc[cb], acc[cb])
+      }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        IKF_MFMA16(fa, wc[cb], acc[cb])
         wc[cb] = wn[cb];
         wn[cb] = IK6_LDW(woffs[cb], k2);
       }
     }
   }
 #undef IK6_LDW
-  __syncthreads();  // every wave is done with A_full before the tail reuses the memory
+  __syncthreads();  // every wave is done with the input rows in LDS before the tail reuses the memory
   skinny16_tail<EPI_RED, NCB>(g, acc, smem, m0, n0, t, lane, kq);
 }
 #undef IKF_MFMA16
@@ -1607,11 +1607,11 @@ static hipError_t launch_skinny16(const FusedGemmArgs& a, hipStream_t s) {
 }
 template <bool EPI_RED, bool DEEP, int NCB>
 static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a, int n_in, hipStream_t s) {
-  size_t smem = entry_gemm16_lds(a.K);
+  size_t smem = entry_gemm16_lds();
   if (smem < skinny16_tail_lds()) smem = skinny16_tail_lds();
   auto kern = k_entry_gemm_skinny16<EPI_RED, DEEP, NCB>;
   static bool lds_ok[64] = {};
-  if (hipError_t err = ensure_dynamic_lds(kern, (size_t)160 * 1024, lds_ok); err != hipSuccess) return err;
+  if (hipError_t err = ensure_dynamic_lds(kern, smem, lds_ok); err != hipSuccess) return err;
   const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / (16 * NCB));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, e, a, n_in);
   return hipGetLastError();
