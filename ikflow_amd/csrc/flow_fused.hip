@@ -1223,12 +1223,12 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e
 // The tile's summation order differs from the 32x32 kernels' (k slices as before, but the last Linear's 32 columns in one MFMA
 // chain): results agree with the other tile shapes to rounding, like every change of tile shape.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int S16_ROWS = 16;
-constexpr size_t skinny16_tail_lds() { return sizeof(float) * ((size_t)KKS * 2 * 4 * 64 + (size_t)(S16_ROWS + 16) * (32 + 4)); }  // (two column blocks: the larger case)
-constexpr size_t skinny16_lds() {
-  return skinny16_tail_lds() > sizeof(float) * 2 * S16_ROWS * (KBK + 4) ? skinny16_tail_lds() : sizeof(float) * 2 * S16_ROWS * (KBK + 4);
+constexpr int S16_ROWS = 16;     // rows of one MFMA row block
+constexpr int S16_MAX_RB = 2;    // row blocks per tile: 1 (16-row tiles) or 2 (32-row tiles, 129 .. 256 rows)
+constexpr size_t skinny16_tail_lds() {  // the largest case: two row blocks x two column blocks
+  return sizeof(float) * ((size_t)KKS * S16_MAX_RB * 2 * 4 * 64 + (size_t)(S16_MAX_RB * S16_ROWS + 16) * (32 + 4));
 }
-constexpr size_t entry_gemm16_lds() { return sizeof(float) * ((size_t)2 * S16_ROWS * ROWBUF + S16_ROWS * EG_ULD); }
+constexpr size_t entry_gemm16_lds() { return sizeof(float) * ((size_t)2 * S16_MAX_RB * S16_ROWS * ROWBUF + S16_MAX_RB * S16_ROWS * EG_ULD); }
 #define IKF_MFMA16(FA, FB, ACC)                                                      \
   {                                                                                  \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.x, FB.x, ACC, 0, 0, 0);            \
@@ -1242,41 +1242,56 @@ __device__ __forceinline__ unsigned wfrag16_off(int kq, int lane, int cb) {
   return (unsigned)(((kq * KKG + (g >> 1)) * 64 + cb * 16 + (lane & 15) + 32 * (g & 1)) * 16);
 }
 
-// tail of the 16-row kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.  Call after a barrier
-// that ends every LDS read of the loop.  acc[cb][v] = tile[row = 4 * (lane / 16) + v][col = 16 cb + lane % 16] over this wave's k slice.
-// NCB = 16-column blocks per tile: 2 (16 x 32 tiles, <= 128 rows) or 1 (16 x 16 tiles, <= 64 rows: twice the workgroups again).
-template <bool EPI_RED, int NCB>
-__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[NCB], float* smem, int m0, int n0, int t,
+// tail of the 16x16x4 kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.  Call after a barrier that
+// ends every LDS access of the caller.  acc[rb][cb][v] = tile[row = 16 rb + 4 (lane / 16) + v][col = 16 cb + lane % 16] over this
+// wave's k slice.  NRB x NCB = 16-row x 16-column blocks per tile: 1 x 1 (<= 64 rows), 1 x 2 (<= 128 rows), 2 x 2 (<= 256 rows).
+template <bool EPI_RED, int NCB, int NRB>
+__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[NRB][NCB], float* smem, int m0, int n0, int t,
                                               int lane, int kq) {
-  constexpr int BN = 16 * NCB, LDT = BN + 4, NT = KKS * 64;
+  constexpr int BN = 16 * NCB, BM = 16 * NRB, LDT = BN + 4, NT = KKS * 64;
+  constexpr int NREG = NRB * NCB * 4;                 // accumulator registers of a lane
+  constexpr int RPW = (NREG + KKS - 1) / KKS;         // registers a wave finishes (2 for 2 x 2 blocks, else 1)
   const int N = g.N;
-  float* red = smem;  // [KKS][NCB][4][64]
+  float* red = smem;  // [KKS][NREG][64]
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
+  for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) red[((kq * NCB + cb) * 4 + v) * 64 + lane] = acc[cb][v];
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[(kq * NREG + (rb * NCB + cb) * 4 + v) * 64 + lane] = acc[rb][cb][v];
   __syncthreads();
-  // wave kq < 4 NCB finishes accumulator register (cb = kq / 4, v = kq % 4) of every lane: the k slices in fixed order 0, 1, ..
-  const bool fin_wave = kq < 4 * NCB;
-  const int cb = kq >> 2, v = kq & 3;
-  float fin = 0.f;
-  const int row = 4 * (lane >> 4) + v, col = cb * 16 + (lane & 15);
-  if (fin_wave) {
+  // wave kq finishes registers RPW kq .. RPW kq + RPW - 1 of every lane: the k slices in fixed order 0, 1, ..
+  float fin[RPW];
+  int frow[RPW], fcol[RPW];
 #pragma unroll
-    for (int q = 0; q < KKS; ++q) fin += red[((q * NCB + cb) * 4 + v) * 64 + lane];
-    fin += g.bias[n0 + col];
-    fin = fin > 0.f ? fin : fin * g.slope;
+  for (int j = 0; j < RPW; ++j) {
+    const int id = RPW * kq + j;  // (rb * NCB + cb) * 4 + v
+    const int v = id & 3, cb = (id >> 2) % NCB, rb = (id >> 2) / NCB;
+    frow[j] = 16 * rb + 4 * (lane >> 4) + v;
+    fcol[j] = 16 * cb + (lane & 15);
+    fin[j] = 0.f;
+    if (id < NREG) {
+#pragma unroll
+      for (int q = 0; q < KKS; ++q) fin[j] += red[(q * NREG + id) * 64 + lane];
+      fin[j] += g.bias[n0 + fcol[j]];
+      fin[j] = fin[j] > 0.f ? fin[j] : fin[j] * g.slope;
+    }
   }
   if constexpr (!EPI_RED) {
-    if (fin_wave) {
-      float* dst = g.C + (size_t)(m0 + row) * N + n0 + col;  // row-padded buffer: unpredicated
-      if (g.wt_stores) __hip_atomic_store(dst, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else *dst = fin;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      if (RPW * kq + j < NREG) {
+        float* dst = g.C + (size_t)(m0 + frow[j]) * N + n0 + fcol[j];  // row-padded buffer: unpredicated
+        if (g.wt_stores) __hip_atomic_store(dst, fin[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *dst = fin[j];
+      }
     }
   } else {
-    float* T = smem + KKS * NCB * 4 * 64;  // [16][LDT], behind red[] (other waves may still be summing)
-    float* Wl = T + S16_ROWS * LDT;        // [16][LDT]: w_last rows (zero beyond n_out), this tile's columns
-    if (fin_wave) T[row * LDT + col] = fin;
+    float* T = smem + KKS * NREG * 64;  // [BM][LDT], behind red[] (other waves may still be summing)
+    float* Wl = T + BM * LDT;           // [16][LDT]: w_last rows (zero beyond n_out), this tile's columns
+#pragma unroll
+    for (int j = 0; j < RPW; ++j)
+      if (RPW * kq + j < NREG) T[frow[j] * LDT + fcol[j]] = fin[j];
     for (int idx = t; idx < 16 * (BN / 4); idx += NT) {
       const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
       floatx4 w = {0.f, 0.f, 0.f, 0.f};
@@ -1284,72 +1299,69 @@ __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floa
       *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = w;
     }
     __syncthreads();
-    if (kq == 0) {  // one wave: P[row][o] = sum over the tile's columns of h[row][col] * w_last[o][col], one MFMA chain
+    if (kq < NRB) {  // wave rb: P[row][o] = sum over the tile's columns of h[row][col] * w_last[o][col] for row block rb, one MFMA chain
       floatx4 pacc = {0.f, 0.f, 0.f, 0.f};
       const int gq = lane >> 4;
 #pragma unroll
       for (int h = 0; h < NCB; ++h) {
-        const floatx4 a4 = *reinterpret_cast<const floatx4*>(T + (lane & 15) * LDT + 16 * h + 4 * gq);
+        const floatx4 a4 = *reinterpret_cast<const floatx4*>(T + (16 * kq + (lane & 15)) * LDT + 16 * h + 4 * gq);
         const floatx4 b4 = *reinterpret_cast<const floatx4*>(Wl + (lane & 15) * LDT + 16 * h + 4 * gq);
         IKF_MFMA16(a4, b4, pacc)
       }
-      // pacc[v] = P[row = 4 * gq + v][o = lane % 16]
-      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + 4 * gq) * IKF_PSTRIDE + (lane & 15);
+      // pacc[v] = P[row = 16 rb + 4 gq + v][o = lane % 16]
+      float* pout = g.P_out + (size_t)(n0 / BN) * g.p_slot_stride + (size_t)(m0 + 16 * kq + 4 * gq) * IKF_PSTRIDE + (lane & 15);
 #pragma unroll
       for (int vv = 0; vv < 4; ++vv) pout[vv * IKF_PSTRIDE] = pacc[vv];
     }
   }
 }
 
-// hidden contraction, 16 x 32 tiles: A rows through two LDS stages (one barrier per k tile), W fragments two k tiles ahead
-// DEEP (K <= 8 k tiles): the workgroup's whole operand stream - 8 x 16 B of A rows per thread, 16 x 16 B of W fragments per lane - is
-// requested up front, tile by tile (sched_barrier keeps that order: tile 0 must not queue behind the rest).  A k tile is only 0.2 us of
-// matrix-pipe time per SIMD here, so two tiles of lead (0.4 us) no longer cover a memory round trip (1 - 2 us).
+// hidden contraction on 16x16x4 MFMAs, tiles of 16 NRB rows x 16 NCB columns, eight waves = eight k slices.  Every operand element
+// feeds exactly ONE wave, so neither W nor A goes through LDS: each lane fetches its own W fragments from the fragment-major image and
+// its own A fragments - row m0 + 16 rb + lane % 16, four k at 16 kq + 4 (lane / 16) of the k tile - straight from the activation
+// buffer (64-byte runs per row and wave; the eight waves together read whole 512-byte row segments).  No LDS traffic and no barrier in
+// the loop.  (The same on the 32x32x2 kernel, whose fragments are 32-byte runs, loses: 0.520 -> 0.533 ms per call at 256 rows.)
+// DEEP (K <= 8 k tiles): the whole operand stream is requested up front, tile by tile (sched_barrier keeps that order: tile 0 must not
+// queue behind the rest): a k tile is only 0.1 - 0.4 us of matrix-pipe time per SIMD, two tiles of lead do not cover a round trip.
 constexpr int kDeepTiles = 8;
-template <bool EPI_RED, bool DEEP, int NCB = 2>
+template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
 __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g) {
-  constexpr int BM = S16_ROWS, BN = 16 * NCB, BK = KBK, NT = KKS * 64, LDK = BK + 4, KQ4 = BK / 4, STAGE = BM * LDK;
-  static_assert(BM * KQ4 == NT, "one float4 of the A tile per thread per stage");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BM = S16_ROWS * NRB, BN = 16 * NCB, BK = KBK;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // the tail's scratch only
   const int M = g.M, N = g.N, K = g.K;
   const int tiles_n = N / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, kq = __builtin_amdgcn_readfirstlane(t >> 6);
-  floatx4 acc[NCB];
+  floatx4 acc[NRB][NCB];
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-  const int arow = t / KQ4, ac4 = t - arow * KQ4;
-  int gr = m0 + arow;
-  gr = gr < M ? gr : M - 1;
-  const unsigned aoff = ((unsigned)gr * (unsigned)K + ac4 * 4) * 4u;
-  const int ldst = arow * LDK + ac4 * 4;
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
   constexpr int WTILE = KKS * KKG * 256;
   const int KT = K / BK;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.Wf), 0, 0x7fffffff, 0x00020000);
   const unsigned wtile0 = (unsigned)(n0 >> 5) * KT;  // the 32-column tile of the fragment-major image this tile lies in
-  unsigned woffs[NCB];
+  unsigned woffs[NCB], afrag[NRB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) woffs[cb] = wfrag16_off(kq, lane, ((n0 >> 4) & 1) + cb);
-  const int fragA = (lane & 15) * LDK + kq * KKW + (lane >> 4) * 4;
-#define IK6_LDA(kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, aoff, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb) {
+    int far = m0 + 16 * rb + (lane & 15);
+    far = far < M ? far : M - 1;
+    afrag[rb] = ((unsigned)far * (unsigned)K + kq * KKW + (lane >> 4) * 4) * 4u;
+  }
+#define IK6_LDA(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
 #define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
   if constexpr (DEEP) {
-    // Every A element of a 16 x 32 tile feeds exactly ONE wave (the eight waves are the eight k slices), so the A rows need no LDS
-    // either: each lane fetches its own fragment - row m0 + lane % 16, four k at 16 kq + 4 (lane / 16) of the k tile - straight from
-    // the activation buffer (64-byte runs per row and wave; the eight waves together read whole 512-byte row segments).  The loop has
-    // no LDS traffic and no barrier.  (The same idea on the 32x32 kernel, whose fragments are 32-byte runs, loses: 0.520 -> 0.533 ms
-    // per call at 256 rows, 1.03 -> 1.17 at 768, where every CU is busy and the narrow loads cost the texture path more than LDS did.)
-    int far = m0 + (lane & 15);
-    far = far < M ? far : M - 1;
-    const unsigned afrag = ((unsigned)far * (unsigned)K + kq * KKW + (lane >> 4) * 4) * 4u;
-    floatx4 aall[kDeepTiles], wall[kDeepTiles][NCB];
+    floatx4 aall[kDeepTiles][NRB], wall[kDeepTiles][NCB];
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {  // unconditional loads (clamped index past the last tile): the compiler counts them
       const int kc = kt < KT ? kt : KT - 1;
-      aall[kt] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, afrag, __builtin_amdgcn_readfirstlane(kc * (BK * 4)), 0));
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) aall[kt][rb] = IK6_LDA(afrag[rb], kc);
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) wall[kt][cb] = IK6_LDW(woffs[cb], kc);
       __builtin_amdgcn_sched_barrier(0);
@@ -1358,54 +1370,46 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
     for (int kt = 0; kt < kDeepTiles; ++kt) {
       if (kt < KT) {  // uniform
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(aall[kt], wall[kt][cb], acc[cb])
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(aall[kt][rb], wall[kt][cb], acc[rb][cb])
       }
     }
   } else {
-    floatx4 rg = IK6_LDA(0);
-    floatx4 wc[NCB], wn[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) wc[cb] = IK6_LDW(woffs[cb], 0);
-    *reinterpret_cast<floatx4*>(smem + ldst) = rg;
+    // two k tiles ahead; branch-free (clamped prefetch index)
+    floatx4 ac[NRB], an[NRB], wc[NCB], wn[NCB];
     const int k1 = KT > 1 ? 1 : 0;
-    rg = IK6_LDA(k1);
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) wn[cb] = IK6_LDW(woffs[cb], k1);
-    __syncthreads();
-    floatx4 fa = *reinterpret_cast<const floatx4*>(smem + fragA);
-    // iteration kt: A tile kt+1 (in rg) -> the other stage, tile kt+2 requested; MFMAs of tile kt; barrier; fragment of tile kt+1.
-    // Branch-free: prefetches past the last tile re-read the last tile (clamped index), the extra LDS image is never consumed.
+    for (int rb = 0; rb < NRB; ++rb) { ac[rb] = IK6_LDA(afrag[rb], 0); an[rb] = IK6_LDA(afrag[rb], k1); }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { wc[cb] = IK6_LDW(woffs[cb], 0); wn[cb] = IK6_LDW(woffs[cb], k1); }
     for (int kt = 0; kt < KT; ++kt) {
-      const int cur = kt & 1, nxt = cur ^ 1;
       const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
-      *reinterpret_cast<floatx4*>(smem + nxt * STAGE + ldst) = rg;
-      rg = IK6_LDA(k2);
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        IKF_MFMA16(fa, wc[cb], acc[cb])
-        wc[cb] = wn[cb];
-        wn[cb] = IK6_LDW(woffs[cb], k2);
-      }
-      __syncthreads();
-      fa = *reinterpret_cast<const floatx4*>(smem + nxt * STAGE + fragA);
+      for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(ac[rb], wc[cb], acc[rb][cb])
+#pragma unroll
+      for (int rb = 0; rb < NRB; ++rb) { ac[rb] = an[rb]; an[rb] = IK6_LDA(afrag[rb], k2); }
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) { wc[cb] = wn[cb]; wn[cb] = IK6_LDW(woffs[cb], k2); }
     }
   }
 #undef IK6_LDA
 #undef IK6_LDW
-  __syncthreads();  // all fragment reads done before the stage area is reused
-  skinny16_tail<EPI_RED, NCB>(g, acc, smem, m0, n0, t, lane, kq);
+  skinny16_tail<EPI_RED, NCB, NRB>(g, acc, smem, m0, n0, t, lane, kq);
 }
 
-// one-launch subnet head, 16-row tiles: pending coupling of the tile's 16 rows, the whole first Linear + LeakyReLU of those rows on
-// the matrix pipe, K loop.  The hidden activation h1 NEVER LEAVES THE REGISTERS: wave kq evaluates exactly the 16-column blocks it
-// will contract - block 8 kt + kq is k slice kq of k tile kt - and the transposed first-Linear product leaves lane l with
-// h1[row = l % 16][16 b + 4 (l / 16) + v] in accumulator register v, which is precisely the A fragment (four consecutive k at offset
-// 4 (l / 16) of the slice) the K loop's MFMAs want.  No LDS tile, no barrier between the first Linear and the loop.
-template <bool EPI_RED, bool DEEP, int NCB = 2>
+// one-launch subnet head on 16x16x4 MFMAs: pending coupling of the tile's 16 NRB rows, the whole first Linear + LeakyReLU of those
+// rows on the matrix pipe, K loop.  The hidden activation h1 NEVER LEAVES THE REGISTERS: wave kq evaluates exactly the 16-column blocks
+// it will contract - block 8 kt + kq is k slice kq of k tile kt - and the transposed first-Linear product leaves lane l with
+// h1[row = 16 rb + l % 16][16 b + 4 (l / 16) + v] in accumulator register v, which is precisely the A fragment (four consecutive k at
+// offset 4 (l / 16) of the slice) the K loop's MFMAs want.  No LDS tile, no barrier between the first Linear and the loop.
+template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
 __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
-  constexpr int BN = 16 * NCB, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS;
-  constexpr int CAP = NCB == 1 ? 64 : 32;  // partial-sum slots read in one round trip (16-column tiles make twice as many slots)
+  constexpr int BN = 16 * NCB, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS * NRB;
   constexpr int BPW_MAX = 8;  // first-Linear 16-column blocks per wave at K = 1024
+  constexpr int CAP = NCB == 1 ? 64 : 32;  // partial-sum slots read in one round trip (16-column tiles make twice as many slots)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = g.K, N = g.N;
   float* cat = smem;               // [R][ROWBUF]   (all three are dead before the tail reuses the memory)
@@ -1467,6 +1471,8 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     if (e.ps.softflow != 0.0f) bv += e.ps.softflow * *reinterpret_cast<const floatx4*>(e.w1soft + cb * 16 + 4 * gq);
     bias4[i] = bv;
   }
+  // one (row, input column) item per thread: R * ROWBUF <= NT
+  static_assert(R * ROWBUF <= NT, "one input element per thread");
   const int ur = t / ROWBUF, uk = t % ROWBUF;
   float pose_v = 0.f;
   if (t < R * ROWBUF && uk >= e.n_x && uk < n_in) {
@@ -1483,36 +1489,45 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     U[ur * EG_ULD + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;  // 0 beyond n_in
   }
   __syncthreads();
-  floatx4 afrag[BPW_MAX];  // afrag[kt][v] = h1[row = lane % 16][k = 128 kt + 16 kq + 4 (lane / 16) + v]: the K loop's A fragments
+  floatx4 afrag[BPW_MAX][NRB];  // afrag[kt][rb][v] = h1[row = 16 rb + lane % 16][k = 128 kt + 16 kq + 4 (lane / 16) + v]: the K loop's A fragments
   {
-    float ua[4];  // "B" fragment of step s: U[row = lane % 16][k = 4 s + lane / 16]
+    float ua[NRB][4];  // "B" fragment of step s: U[row = 16 rb + lane % 16][k = 4 s + lane / 16]
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) ua[s4] = U[cl * EG_ULD + 4 * s4 + gq];
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) ua[rb][s4] = U[(16 * rb + cl) * EG_ULD + 4 * s4 + gq];
 #pragma unroll
     for (int i = 0; i < BPW_MAX; ++i) {
-      floatx4 a1 = bias4[i];
-      if (i < bpw) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-          if (4 * s4 < n_in) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s4], ua[s4], a1, 0, 0, 0);  // k past n_in: 0 * 0
-        a1.x = a1.x > 0.f ? a1.x : a1.x * e.slope;
-        a1.y = a1.y > 0.f ? a1.y : a1.y * e.slope;
-        a1.z = a1.z > 0.f ? a1.z : a1.z * e.slope;
-        a1.w = a1.w > 0.f ? a1.w : a1.w * e.slope;
+      for (int rb = 0; rb < NRB; ++rb) {
+        floatx4 a1 = bias4[i];
+        if (i < bpw) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+            if (4 * s4 < n_in) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[i][s4], ua[rb][s4], a1, 0, 0, 0);  // k past n_in: 0 * 0
+          a1.x = a1.x > 0.f ? a1.x : a1.x * e.slope;
+          a1.y = a1.y > 0.f ? a1.y : a1.y * e.slope;
+          a1.z = a1.z > 0.f ? a1.z : a1.z * e.slope;
+          a1.w = a1.w > 0.f ? a1.w : a1.w * e.slope;
+        }
+        afrag[i][rb] = a1;
       }
-      afrag[i] = a1;
     }
   }
-  floatx4 acc[NCB];
+  floatx4 acc[NRB][NCB];
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = floatx4{0.f, 0.f, 0.f, 0.f};
   static_assert(BPW_MAX == kDeepTiles, "one first-Linear block per k tile");
   if constexpr (DEEP) {
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
       if (kt < KT) {  // uniform; no LDS, no barrier
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(afrag[kt], wall[kt][cb], acc[cb])
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(afrag[kt][rb], wall[kt][cb], acc[rb][cb])
       }
     }
   } else {
@@ -1521,7 +1536,9 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
       const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
       if (kt < KT) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(afrag[kt], wc[cb], acc[cb])
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) IKF_MFMA16(afrag[kt][rb], wc[cb], acc[rb][cb])
       }
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
@@ -1532,7 +1549,7 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   }
 #undef IK6_LDW
   __syncthreads();  // every wave is done with the input rows in LDS before the tail reuses the memory
-  skinny16_tail<EPI_RED, NCB>(g, acc, smem, m0, n0, t, lane, kq);
+  skinny16_tail<EPI_RED, NCB, NRB>(g, acc, smem, m0, n0, t, lane, kq);
 }
 #undef IKF_MFMA16
 
@@ -1595,32 +1612,33 @@ static hipError_t launch_entry_gemm_t(const EntryArgs& e, const FusedGemmArgs& a
 }
 
 int g_deep16 = 1;  // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole stream
-template <bool EPI_RED, bool DEEP, int NCB>
+template <bool EPI_RED, bool DEEP, int NCB, int NRB = 1>
 static hipError_t launch_skinny16(const FusedGemmArgs& a, hipStream_t s) {
-  constexpr size_t smem = skinny16_lds();
-  auto kern = k_flow_gemm_skinny16<EPI_RED, DEEP, NCB>;
+  constexpr size_t smem = skinny16_tail_lds();
+  auto kern = k_flow_gemm_skinny16<EPI_RED, DEEP, NCB, NRB>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
-  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / (16 * NCB));
+  const long long grid = (((long long)a.M + S16_ROWS * NRB - 1) / (S16_ROWS * NRB)) * (a.N / (16 * NCB));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, a);
   return hipGetLastError();
 }
-template <bool EPI_RED, bool DEEP, int NCB>
+template <bool EPI_RED, bool DEEP, int NCB, int NRB = 1>
 static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a, int n_in, hipStream_t s) {
   size_t smem = entry_gemm16_lds();
   if (smem < skinny16_tail_lds()) smem = skinny16_tail_lds();
-  auto kern = k_entry_gemm_skinny16<EPI_RED, DEEP, NCB>;
+  auto kern = k_entry_gemm_skinny16<EPI_RED, DEEP, NCB, NRB>;
   static bool lds_ok[64] = {};
   if (hipError_t err = ensure_dynamic_lds(kern, smem, lds_ok); err != hipSuccess) return err;
-  const long long grid = (((long long)a.M + S16_ROWS - 1) / S16_ROWS) * (a.N / (16 * NCB));
+  const long long grid = (((long long)a.M + S16_ROWS * NRB - 1) / (S16_ROWS * NRB)) * (a.N / (16 * NCB));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, e, a, n_in);
   return hipGetLastError();
 }
 
 // true when the first hidden contraction of a subnet can run as k_entry_gemm_skinny for this batch
 bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out) {
-  if (cfg == 9 || cfg == 10) {  // kSkinny16Cfg: 16 x 32 tiles; kSkinny16x16Cfg: 16 x 16 tiles
-    const long long tiles = ((rows + S16_ROWS - 1) / S16_ROWS) * (width / (cfg == 9 ? 32 : 16));
+  if (cfg == 9 || cfg == 10 || cfg == 11) {  // kSkinny16Cfg: 16 x 32 tiles; kSkinny16x16Cfg: 16 x 16; kSkinny32x32v2Cfg: 32 x 32 on 16x16x4
+    const int br = cfg == 11 ? 32 : 16;
+    const long long tiles = ((rows + br - 1) / br) * (width / (cfg == 10 ? 16 : 32));
     return tiles <= 512 && width <= 2048 && width % (2 * KBK) == 0 && (width / 16) % KKS == 0 && (width / 16) / KKS <= 8 &&
            D <= ROWBUF && n_out <= ROWBUF;  // (its 69 KB of LDS at width 1024 lets two workgroups share a CU)
   }
@@ -1646,6 +1664,11 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
       return epi_red ? launch_entry_gemm16<true, true, 1>(e, a, n_in, s) : launch_entry_gemm16<false, true, 1>(e, a, n_in, s);
     return epi_red ? launch_entry_gemm16<true, false, 1>(e, a, n_in, s) : launch_entry_gemm16<false, false, 1>(e, a, n_in, s);
   }
+  if (cfg == 11) {
+    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
+      return epi_red ? launch_entry_gemm16<true, true, 2, 2>(e, a, n_in, s) : launch_entry_gemm16<false, true, 2, 2>(e, a, n_in, s);
+    return epi_red ? launch_entry_gemm16<true, false, 2, 2>(e, a, n_in, s) : launch_entry_gemm16<false, false, 2, 2>(e, a, n_in, s);
+  }
   if (cfg == 4) return epi_red ? launch_entry_gemm_t<true, 2>(e, a, n_in, s) : launch_entry_gemm_t<false, 2>(e, a, n_in, s);
   return epi_red ? launch_entry_gemm_t<true, 1>(e, a, n_in, s) : launch_entry_gemm_t<false, 1>(e, a, n_in, s);
 }
@@ -1655,16 +1678,20 @@ constexpr int kSkinnyCfg = 4;    // k_flow_gemm_skinny<.., 2>: 32x64 tiles
 constexpr int kSkinny32Cfg = 6;  // k_flow_gemm_skinny<.., 1>: 32x32 tiles (5 is the 4-wave probe of the large tile)
 constexpr int kSkinny16Cfg = 9;     // k_flow_gemm_skinny16<.., 2>: 16x32 tiles on v_mfma_f32_16x16x4_f32 (<= 128 rows)
 constexpr int kSkinny16x16Cfg = 10;  // k_flow_gemm_skinny16<.., 1>: 16x16 tiles (<= 64 rows)
+constexpr int kSkinny32v2Cfg = 11;   // k_flow_gemm_skinny16<.., 2, 2>: 32x32 tiles built from 16x16x4 MFMAs (129 .. 256 rows)
+int g_skinny32v2 = 0;                // opt-in (r03: 0.519 - 0.543 against 0.499 - 0.519 ms per call on the 32x32x2 kernels - it loses)
 int g_skinny16x16 = 1;               // probes / tests: 0 = batches of <= 64 rows keep the 16x32 tiles
 int g_skinny16 = 1;              // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles
 int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_skinny32_cfg() { return kSkinny32Cfg; }
 int fused_skinny16_cfg() { return kSkinny16Cfg; }
 int fused_skinny16x16_cfg() { return kSkinny16x16Cfg; }
+int fused_skinny32v2_cfg() { return kSkinny32v2Cfg; }
 int fused_pick_cfg(long long rows, int width) {
   if (width % KBN == 0 && width % (2 * KBK) == 0) {
     if (rows <= 64 && g_skinny16 != 0 && g_skinny16x16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 16) <= 256) return kSkinny16x16Cfg;
     if (rows <= 128 && g_skinny16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32) <= 256) return kSkinny16Cfg;
+    if (rows <= 256 && g_skinny32v2 != 0 && g_skinny16 != 0 && ((rows + 31) / 32) * (width / 32) <= 256 && width <= kDeepTiles * KBK) return kSkinny32v2Cfg;
     if (rows <= 256) return kSkinny32Cfg;
     if (rows <= 512) return kSkinnyCfg;
     if (rows <= 768) return kSkinny32Cfg;  // three co-resident 32x32 workgroups per CU: 1.00 ms against 1.06 (64x64 tiles)
@@ -1689,7 +1716,7 @@ int fused_pick_cfg(long long rows, int width) {
 }
 // partial-sum slots of the last Linear: one per 64 columns, except the 32-column small-batch tiles (half slots)
 int fused_slots(int cfg, int width) {
-  return cfg == kSkinny16x16Cfg ? width / 16 : (cfg == kSkinny32Cfg || cfg == kSkinny16Cfg) ? width / 32 : width / 64;
+  return cfg == kSkinny16x16Cfg ? width / 16 : (cfg == kSkinny32Cfg || cfg == kSkinny16Cfg || cfg == kSkinny32v2Cfg) ? width / 32 : width / 64;
 }
 int fused_max_slots(int width) { return width / 16; }
 const char* fused_kernel_name() { return "k_flow_gemm"; }
@@ -1743,9 +1770,13 @@ hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArg
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
-  if (cfg == kSkinny16Cfg || cfg == kSkinny16x16Cfg) {
+  if (cfg == kSkinny16Cfg || cfg == kSkinny16x16Cfg || cfg == kSkinny32v2Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
     const bool deep = g_deep16 != 0 && a.K <= kDeepTiles * KBK;
+    if (cfg == kSkinny32v2Cfg) {
+      if (deep) return epi_red ? launch_skinny16<true, true, 2, 2>(a, s) : launch_skinny16<false, true, 2, 2>(a, s);
+      return epi_red ? launch_skinny16<true, false, 2, 2>(a, s) : launch_skinny16<false, false, 2, 2>(a, s);
+    }
     if (cfg == kSkinny16Cfg) {
       if (deep) return epi_red ? launch_skinny16<true, true, 2>(a, s) : launch_skinny16<false, true, 2>(a, s);
       return epi_red ? launch_skinny16<true, false, 2>(a, s) : launch_skinny16<false, false, 2>(a, s);

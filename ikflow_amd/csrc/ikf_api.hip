@@ -639,6 +639,15 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_tail = variant - 120;
     return IKF_OK;
   }
+  if (variant == 162 || variant == 163) {  // 129 .. 256 rows on 32x32 tiles built from 16x16x4 MFMAs: off (default) / on (process-wide)
+    g_skinny32v2 = variant - 162;
+    return IKF_OK;
+  }
+  if (variant == 164) {  // ... forced (tile config 11)
+    m->gemm_variant = 100;
+    m->tile_cfg = 11;
+    return IKF_OK;
+  }
   if (variant == 160 || variant == 161) {  // fused pipeline with the 16x32 / 16x16 small-batch tiles forced (tile config 9 / 10)
     m->gemm_variant = 100;
     m->tile_cfg = variant - 151;
@@ -705,7 +714,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   // f16x3 mode: its own tile choice; the partial-sum slots follow the kernel that writes them
   // (f16x3 mode, batches that pick the 16-row f32 tiles - <= 128 rows: the exact-f32 kernels are the faster ones there since round 3,
   // 0.43 against 0.46 ms per call, so the mode steps aside; a forced tile configuration keeps the split kernels)
-  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && (cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg()));
+  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && (cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg() || cfg == fused_skinny32v2_cfg()));
   int scfg = -1;
   if (split) {
     scfg = (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width);
@@ -753,7 +762,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     // one launch takes as long as the two it replaces (18.4 us against 5.5 + 13.0), so those keep the two-launch form
     // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
     const bool one_launch = !tail && !split &&
-                            (m->fuse_entry == 2 || (m->fuse_entry == 1 && (cfg == fused_skinny32_cfg() || cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg()))) &&
+                            (m->fuse_entry == 2 || (m->fuse_entry == 1 && (cfg == fused_skinny32_cfg() || cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg() || cfg == fused_skinny32v2_cfg()))) &&
                             entry_gemm_ok(cfg, nr, d.width, d.D, pend.P ? pend.n_out : 0) &&
                             frag_image(m, 2 * b + which - 1, 0) != nullptr;
     if (!one_launch && !entry_done) IKF_HIP(launch_subnet_entry(w.n_x + d.n_pose, e, s));

@@ -211,6 +211,8 @@ int fused_skinny_cfg();
 int fused_skinny32_cfg();
 int fused_skinny16_cfg();
 int fused_skinny16x16_cfg();
+int fused_skinny32v2_cfg();
+extern int g_skinny32v2;   // probes / tests: 0 = 129 .. 256 rows keep the 32x32x2 kernels
 extern int g_skinny16x16;  // probes / tests: 0 = batches of <= 64 rows keep the 16x32 tiles
 extern int g_deep16;    // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole operand stream
 extern int g_skinny16;  // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles

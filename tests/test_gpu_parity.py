@@ -1400,7 +1400,7 @@ def test_sixteen_row_tiles_for_small_batches(kw):
             eng.set_gemm_variant(151); eng.set_gemm_variant(159); eng.set_gemm_variant(111)
             assert torch.equal(outs[(151, 111)], s.generate_ik_solutions(P, **kw_n).cpu())  # deterministic
         eng.set_gemm_variant(151); eng.set_gemm_variant(111)
-        for forced in (160, 161):  # the 16x32 / 16x16 tiles forced for a batch that would not pick them
+        for forced in (160, 161, 164):  # 16x32 / 16x16 / 32x32-on-16x16x4 tiles forced for a batch that would not pick them
             eng.set_gemm_variant(forced)
             got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
             assert ((got - ref).abs() / scale).max().item() <= FLOW_TOL, forced
