@@ -7,7 +7,12 @@ north star asks for ("huge pose batches shard embarrassingly across the 8 GPUs o
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
+
+# RCCL exchanges peer memory handles when the group forms; this host driver supports the dmabuf form only.  Harmless when the
+# launcher already exported it; it has to be in the environment before the HIP runtime initialises.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
