@@ -136,6 +136,12 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP engine has not been built (run `python -m ikflow_amd.build`). "
             "ikflow_amd has no CPU path."
         )
+    # torch FIRST: it ships its own copy of the HIP runtime (torch/lib/libamdhip64.so); if this library were loaded before
+    # torch, the loader would bind it to /opt/rocm's copy and the process would hold two HIP runtimes, the second of which sees
+    # no device ("ikf_create: no HIP device visible" although torch.cuda.is_available()).  With torch's copy already mapped, this
+    # library's libamdhip64.so.7 dependency resolves to it.  (A C / C++ client without torch links /opt/rocm's copy alone.)
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

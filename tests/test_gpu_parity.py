@@ -1559,3 +1559,18 @@ def test_repeated_interleaved_calls_are_bit_identical():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "determinism_soak.py"), "6"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MISMATCH" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_library_loaded_before_torch_still_sees_the_gpu():
+    """`__graft_entry__.build()` then `smoke()` in ONE process: the ctypes binding is loaded before anything has imported torch.
+    torch ships its own copy of the HIP runtime; `_lib.load()` imports torch first so the process holds one runtime, not two (with
+    two, `ikf_create` saw no device although torch.cuda.is_available())."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("from ikflow_amd import _lib; _lib.load()\n"
+            "import __graft_entry__ as g\n"
+            "g.build(); g.smoke()\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
