@@ -1611,7 +1611,6 @@ static hipError_t launch_entry_gemm_t(const EntryArgs& e, const FusedGemmArgs& a
   return hipGetLastError();
 }
 
-int g_deep16 = 1;  // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole stream
 template <bool EPI_RED, bool DEEP, int NCB, int NRB = 1>
 static hipError_t launch_skinny16(const FusedGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = skinny16_tail_lds();
@@ -1655,17 +1654,17 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
       e.width != a.K)
     return hipErrorInvalidValue;
   if (cfg == 9) {
-    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
+    if ((a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK)
       return epi_red ? launch_entry_gemm16<true, true, 2>(e, a, n_in, s) : launch_entry_gemm16<false, true, 2>(e, a, n_in, s);
     return epi_red ? launch_entry_gemm16<true, false, 2>(e, a, n_in, s) : launch_entry_gemm16<false, false, 2>(e, a, n_in, s);
   }
   if (cfg == 10) {
-    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
+    if ((a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK)
       return epi_red ? launch_entry_gemm16<true, true, 1>(e, a, n_in, s) : launch_entry_gemm16<false, true, 1>(e, a, n_in, s);
     return epi_red ? launch_entry_gemm16<true, false, 1>(e, a, n_in, s) : launch_entry_gemm16<false, false, 1>(e, a, n_in, s);
   }
   if (cfg == 11) {
-    if (g_deep16 != 0 && a.K <= kDeepTiles * KBK)
+    if ((a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK)
       return epi_red ? launch_entry_gemm16<true, true, 2, 2>(e, a, n_in, s) : launch_entry_gemm16<false, true, 2, 2>(e, a, n_in, s);
     return epi_red ? launch_entry_gemm16<true, false, 2, 2>(e, a, n_in, s) : launch_entry_gemm16<false, false, 2, 2>(e, a, n_in, s);
   }
@@ -1679,19 +1678,18 @@ constexpr int kSkinny32Cfg = 6;  // k_flow_gemm_skinny<.., 1>: 32x32 tiles (5 is
 constexpr int kSkinny16Cfg = 9;     // k_flow_gemm_skinny16<.., 2>: 16x32 tiles on v_mfma_f32_16x16x4_f32 (<= 128 rows)
 constexpr int kSkinny16x16Cfg = 10;  // k_flow_gemm_skinny16<.., 1>: 16x16 tiles (<= 64 rows)
 constexpr int kSkinny32v2Cfg = 11;   // k_flow_gemm_skinny16<.., 2, 2>: 32x32 tiles built from 16x16x4 MFMAs (129 .. 256 rows)
-int g_skinny32v2 = 0;                // opt-in (r03: 0.519 - 0.543 against 0.499 - 0.519 ms per call on the 32x32x2 kernels - it loses)
-int g_skinny16x16 = 1;               // probes / tests: 0 = batches of <= 64 rows keep the 16x32 tiles
-int g_skinny16 = 1;              // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles
+                                     // opt-in, IKF_TUNE_ROWS32_V2 (r03: 0.519 - 0.543 against 0.499 - 0.519 ms per call on the 32x32x2 kernels)
 int fused_skinny_cfg() { return kSkinnyCfg; }
 int fused_skinny32_cfg() { return kSkinny32Cfg; }
 int fused_skinny16_cfg() { return kSkinny16Cfg; }
 int fused_skinny16x16_cfg() { return kSkinny16x16Cfg; }
 int fused_skinny32v2_cfg() { return kSkinny32v2Cfg; }
-int fused_pick_cfg(long long rows, int width) {
+int fused_pick_cfg(long long rows, int width, int tune) {
   if (width % KBN == 0 && width % (2 * KBK) == 0) {
-    if (rows <= 64 && g_skinny16 != 0 && g_skinny16x16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 16) <= 256) return kSkinny16x16Cfg;
-    if (rows <= 128 && g_skinny16 != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32) <= 256) return kSkinny16Cfg;
-    if (rows <= 256 && g_skinny32v2 != 0 && g_skinny16 != 0 && ((rows + 31) / 32) * (width / 32) <= 256 && width <= kDeepTiles * KBK) return kSkinny32v2Cfg;
+    const bool rows16 = (tune & IKF_TUNE_ROWS16) != 0;
+    if (rows <= 64 && rows16 && (tune & IKF_TUNE_TILES16) != 0 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 16) <= 256) return kSkinny16x16Cfg;
+    if (rows <= 128 && rows16 && ((rows + S16_ROWS - 1) / S16_ROWS) * (width / 32) <= 256) return kSkinny16Cfg;
+    if (rows <= 256 && rows16 && (tune & IKF_TUNE_ROWS32_V2) != 0 && ((rows + 31) / 32) * (width / 32) <= 256 && width <= kDeepTiles * KBK) return kSkinny32v2Cfg;
     if (rows <= 256) return kSkinny32Cfg;
     if (rows <= 512) return kSkinnyCfg;
     if (rows <= 768) return kSkinny32Cfg;  // three co-resident 32x32 workgroups per CU: 1.00 ms against 1.06 (64x64 tiles)
@@ -1772,7 +1770,7 @@ hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipSt
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
   if (cfg == kSkinny16Cfg || cfg == kSkinny16x16Cfg || cfg == kSkinny32v2Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
-    const bool deep = g_deep16 != 0 && a.K <= kDeepTiles * KBK;
+    const bool deep = (a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK;
     if (cfg == kSkinny32v2Cfg) {
       if (deep) return epi_red ? launch_skinny16<true, true, 2, 2>(a, s) : launch_skinny16<false, true, 2, 2>(a, s);
       return epi_red ? launch_skinny16<true, false, 2, 2>(a, s) : launch_skinny16<false, false, 2, 2>(a, s);

@@ -62,6 +62,7 @@ struct ikf_model {
   // the next subnet's entry phase in the tail of the last hidden contraction (TailSync).  OFF by default: measured slower than the
   // k_subnet_entry launch it replaces (r03: +3.6 % per call at 4096 rows, +7.4 % at 512) - kept as a tested,
   // bit-identical opt-in (ikf_set_gemm_variant 121) because it is the priced answer to "hand over inside the launch"
+  int tune = IKF_TUNE_DEFAULT;  // IKF_TUNE_* switches of the small-batch kernels (ikf_set_gemm_variant 150 .. 163)
   int fuse_tail = 0;
   // Activation stores write-through (sc1): the lines go to memory as they are written instead of sitting dirty in the XCD L2s until the
   // launch's end flushes them (r03, tools/variant_ab.py: 3.261 -> 3.229 ms per call at 4096 rows with the contractions' stores
@@ -623,12 +624,12 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_entry = variant - 110;
     return IKF_OK;
   }
-  if (variant == 152 || variant == 153) {  // 16-row kernels: whole operand stream up front off / on (process-wide probe / test switch)
-    g_deep16 = variant - 152;
+  if (variant == 152 || variant == 153) {  // 16-row kernels: whole operand stream up front off / on
+    m->tune = variant == 153 ? (m->tune | IKF_TUNE_DEEP16) : (m->tune & ~IKF_TUNE_DEEP16);
     return IKF_OK;
   }
   if (variant == 150 || variant == 151) {  // <= 128 rows on 16x32 tiles (v_mfma_f32_16x16x4_f32): off / on
-    g_skinny16 = variant - 150;             // (process-wide: a probe / test switch, not a per-handle setting)
+    m->tune = variant == 151 ? (m->tune | IKF_TUNE_ROWS16) : (m->tune & ~IKF_TUNE_ROWS16);
     return IKF_OK;
   }
   if (variant >= 130 && variant <= 134) {  // write-through activation stores: none / contractions / entry kernel / both / by batch size
@@ -639,8 +640,8 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->fuse_tail = variant - 120;
     return IKF_OK;
   }
-  if (variant == 162 || variant == 163) {  // 129 .. 256 rows on 32x32 tiles built from 16x16x4 MFMAs: off (default) / on (process-wide)
-    g_skinny32v2 = variant - 162;
+  if (variant == 162 || variant == 163) {  // 129 .. 256 rows on 32x32 tiles built from 16x16x4 MFMAs: off (default) / on
+    m->tune = variant == 163 ? (m->tune | IKF_TUNE_ROWS32_V2) : (m->tune & ~IKF_TUNE_ROWS32_V2);
     return IKF_OK;
   }
   if (variant == 164) {  // ... forced (tile config 11)
@@ -653,8 +654,8 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->tile_cfg = variant - 151;
     return IKF_OK;
   }
-  if (variant == 158 || variant == 159) {  // <= 64 rows on 16x16 tiles: off / on (process-wide probe / test switch)
-    g_skinny16x16 = variant - 158;
+  if (variant == 158 || variant == 159) {  // <= 64 rows on 16x16 tiles: off / on
+    m->tune = variant == 159 ? (m->tune | IKF_TUNE_TILES16) : (m->tune & ~IKF_TUNE_TILES16);
     return IKF_OK;
   }
   if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
@@ -710,7 +711,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
-  const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width);
+  const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width, m->tune);
   // f16x3 mode: its own tile choice; the partial-sum slots follow the kernel that writes them
   // (f16x3 mode, batches that pick the 16-row f32 tiles - <= 128 rows: the exact-f32 kernels are the faster ones there since round 3,
   // 0.43 against 0.46 ms per call, so the mode steps aside; a forced tile configuration keeps the split kernels)
@@ -755,6 +756,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     FusedGemmArgs g{};
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
     g.wt_stores = m->wt_stores < 0 ? 1 : (m->wt_stores & 1);
+    g.tune = m->tune;
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
     const int n_mid = d.n_hidden - 1;
     // small batches: the entry kernel and the first hidden contraction run as one launch (k_entry_gemm_skinny).  In the
@@ -1220,12 +1222,13 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
   if (fused) {
     // the contraction that reads its A operand from HBM and reduces the last Linear in its epilogue (h -> partials)
     g.M = (int)rows; g.N = m->dims.width; g.K = m->dims.width; g.slope = m->dims.slope;
+    g.tune = m->tune;
     g.A = m->hA; g.W = w.w_mid[m->dims.n_hidden - 2]; g.bias = w.b_mid[m->dims.n_hidden - 2];
     g.Wf = frag_image(m, 0, m->dims.n_hidden - 2);
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = m->chunk_rows * IKF_PSTRIDE;
   }
   auto launch = [&]() -> hipError_t {
-    if (fused) return launch_flow_gemm(true, (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(rows, m->dims.width), g, s);
+    if (fused) return launch_flow_gemm(true, (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(rows, m->dims.width, m->tune), g, s);
     return launch_gemm_lrelu(variant, m->hA, w.w_mid[0], w.b_mid[0], m->hB, rows, m->dims.width, m->dims.width,
                              m->dims.slope, s);
   };

@@ -128,6 +128,7 @@ struct FusedGemmArgs {
   int M, N, K;
   float slope;
   int wt_stores;      // activation stores write-through (sc1), see EntryArgs
+  int tune;           // IKF_TUNE_* bits the launcher looks at (IKF_TUNE_DEEP16)
   // partial-sum epilogue: P_out[slot][row][o] = sum over the tile's columns of lrelu(...)[row][col] * w_last[o][col]
   const float* w_last;  // [n_out][N]
   int n_out;
@@ -147,7 +148,15 @@ struct FinalizeArgs {
   int sigmoid;         // apply 1/(1+exp(-x)) before the linear transform (sigmoid_on_output graph)
   float* q_out;        // [M][ndof]
 };
-int fused_pick_cfg(long long rows, int width);  // tile configuration for a batch (-1: width not supported)
+// per-handle tuning switches of the small-batch kernels (ikf_set_gemm_variant 150 .. 163); every combination computes the same function
+enum : int {
+  IKF_TUNE_ROWS16 = 1,     // batches of <= 128 rows on 16-row tiles (v_mfma_f32_16x16x4_f32)
+  IKF_TUNE_DEEP16 = 2,     // those kernels request their whole operand stream up front
+  IKF_TUNE_TILES16 = 4,    // batches of <= 64 rows on 16 x 16 tiles
+  IKF_TUNE_ROWS32_V2 = 8,  // 129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs (off by default: measured slower)
+  IKF_TUNE_DEFAULT = IKF_TUNE_ROWS16 | IKF_TUNE_DEEP16 | IKF_TUNE_TILES16,
+};
+int fused_pick_cfg(long long rows, int width, int tune = IKF_TUNE_DEFAULT);  // tile configuration for a batch (-1: width not supported)
 int fused_slots(int cfg, int width);            // partial-sum slots that configuration produces per row
 int fused_max_slots(int width);
 hipError_t launch_subnet_entry(int n_in, const EntryArgs& e, hipStream_t s);
@@ -212,10 +221,6 @@ int fused_skinny32_cfg();
 int fused_skinny16_cfg();
 int fused_skinny16x16_cfg();
 int fused_skinny32v2_cfg();
-extern int g_skinny32v2;   // probes / tests: 0 = 129 .. 256 rows keep the 32x32x2 kernels
-extern int g_skinny16x16;  // probes / tests: 0 = batches of <= 64 rows keep the 16x32 tiles
-extern int g_deep16;    // probes / tests: 0 = the 16-row kernels fetch two k tiles ahead instead of their whole operand stream
-extern int g_skinny16;  // probes / tests: 0 = batches of <= 128 rows keep the 32x32 tiles
 hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream_t s);
 hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, int* d_flag, hipStream_t s);
 const char* split_kernel_name();

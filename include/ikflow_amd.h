@@ -248,10 +248,10 @@ const char* ikf_dominant_kernel_name(void);
  *   110 / 111 / 112  small-batch one-launch subnet head (entry kernel + first hidden contraction): off / automatic (default) / forced;
  *   120 / 121        next subnet's entry phase inside the preceding launch (row-tile arrival counter): off (default) / on;
  *   130 .. 134       write-through (sc1) activation stores: none / contractions / entry kernel / both / by batch size (default);
- *   150 / 151        batches of <= 128 rows on 16 x 32 tiles (v_mfma_f32_16x16x4_f32): off / on (default)   [process-wide]
- *   152 / 153        the 16-row kernels request their whole operand stream up front: off / on (default)      [process-wide]
- *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced                   [process-wide]
- *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced [process-wide]
+ *   150 / 151        batches of <= 128 rows on 16 x 32 tiles (v_mfma_f32_16x16x4_f32): off / on (default)
+ *   152 / 153        the 16-row kernels request their whole operand stream up front: off / on (default)
+ *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced
+ *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced
  * Returns IKF_ERR_BAD_ARGUMENT if unknown. */
 ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 
