@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256) void k_flow_finalize(FinalizeArgs f) {
 // rounding, not bit for bit, across the 512-row boundary.)
 // ---------------------------------------------------------------------------------------------------------------
 // NH = column halves per workgroup: 2 -> 32x64 tiles, 16 waves (257..512 rows: <= 256 tiles); 1 -> 32x32 tiles, 8 waves
-// (<= 256 rows: still <= 256 tiles, and half the matrix-pipe time per stage - the per-launch latency drops by a third).
+// (129 .. 256 rows - <= 128 rows run on the 16-row tiles of the 16x16x4 kernels further down - and 513 .. 768 rows, three workgroups
+// per CU: still <= 256 tiles up to 256 rows, and half the matrix-pipe time per stage - the per-launch latency drops by a third).
 constexpr int KBM = 32, KBN = 64, KBK = 128;
 constexpr int KKS = 8;               // k-slices per tile (waves = NH column halves x KKS)
 constexpr int KKW = KBK / KKS;       // k per wave per tile (16)

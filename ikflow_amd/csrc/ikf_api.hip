@@ -760,7 +760,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
     const int n_mid = d.n_hidden - 1;
     // small batches: the entry kernel and the first hidden contraction run as one launch (k_entry_gemm_skinny).  In the
-    // chain it pays with the 32x32 tiles (<= 256 rows: 0.56 -> 0.53 ms per call); with the 32x64 tiles (257..512 rows) the
+    // chain it pays with the 32x32 tiles (129 .. 256 rows: 0.56 -> 0.53 ms per call) and the 16-row tiles (<= 128 rows, where it
+    // exists only in this form worth having: r03); with the 32x64 tiles (257..512 rows) the
     // one launch takes as long as the two it replaces (18.4 us against 5.5 + 13.0), so those keep the two-launch form
     // unless it is forced (fuse_entry == 2, ikf_set_gemm_variant 112)
     const bool one_launch = !tail && !split &&
