@@ -1246,9 +1246,32 @@ __device__ __forceinline__ unsigned wfrag16_off(int kq, int lane, int cb) {
 // tail of the 16x16x4 kernels: k-slice reduction + bias / LeakyReLU + store or last-Linear partial sums.  Call after a barrier that
 // ends every LDS access of the caller.  acc[rb][cb][v] = tile[row = 16 rb + 4 (lane / 16) + v][col = 16 cb + lane % 16] over this
 // wave's k slice.  NRB x NCB = 16-row x 16-column blocks per tile: 1 x 1 (<= 64 rows), 1 x 2 (<= 128 rows), 2 x 2 (<= 256 rows).
+// What the tail reads from memory - the bias of the columns a wave finishes and (EPI_RED) this thread's piece of the last Linear's
+// slice - is requested at the START of the kernel (skinny16_prefetch): fetched in the tail each costs a memory round trip there.
+template <int NCB, int NRB>
+struct Skinny16Pre {
+  static constexpr int NREG = NRB * NCB * 4, RPW = (NREG + KKS - 1) / KKS;
+  float bias[RPW];
+  floatx4 wl;  // w_last[o = t / (BN / 4)][n0 + 4 (t % (BN / 4)) ..] for t < 16 BN / 4 (zero beyond n_out)
+};
 template <bool EPI_RED, int NCB, int NRB>
-__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[NRB][NCB], float* smem, int m0, int n0, int t,
-                                              int lane, int kq) {
+__device__ __forceinline__ void skinny16_prefetch(const FusedGemmArgs& g, int n0, int t, int lane, int kq, Skinny16Pre<NCB, NRB>& pre) {
+  constexpr int BN = 16 * NCB, NREG = NRB * NCB * 4, RPW = Skinny16Pre<NCB, NRB>::RPW;
+#pragma unroll
+  for (int j = 0; j < RPW; ++j) {
+    const int id = RPW * kq + j;
+    pre.bias[j] = id < NREG ? g.bias[n0 + 16 * ((id >> 2) % NCB) + (lane & 15)] : 0.f;
+  }
+  pre.wl = floatx4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI_RED) {
+    static_assert(16 * (BN / 4) <= KKS * 64, "one float4 of the last Linear's slice per thread");
+    const int o = t / (BN / 4), c4 = t - o * (BN / 4);
+    if (t < 16 * (BN / 4) && o < g.n_out) pre.wl = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * g.N + n0 + c4 * 4);
+  }
+}
+template <bool EPI_RED, int NCB, int NRB>
+__device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[NRB][NCB], const Skinny16Pre<NCB, NRB>& pre,
+                                              float* smem, int m0, int n0, int t, int lane, int kq) {
   constexpr int BN = 16 * NCB, BM = 16 * NRB, LDT = BN + 4, NT = KKS * 64;
   constexpr int NREG = NRB * NCB * 4;                 // accumulator registers of a lane
   constexpr int RPW = (NREG + KKS - 1) / KKS;         // registers a wave finishes (2 for 2 x 2 blocks, else 1)
@@ -1274,7 +1297,7 @@ __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floa
     if (id < NREG) {
 #pragma unroll
       for (int q = 0; q < KKS; ++q) fin[j] += red[(q * NREG + id) * 64 + lane];
-      fin[j] += g.bias[n0 + fcol[j]];
+      fin[j] += pre.bias[j];
       fin[j] = fin[j] > 0.f ? fin[j] : fin[j] * g.slope;
     }
   }
@@ -1293,11 +1316,9 @@ __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floa
 #pragma unroll
     for (int j = 0; j < RPW; ++j)
       if (RPW * kq + j < NREG) T[frow[j] * LDT + fcol[j]] = fin[j];
-    for (int idx = t; idx < 16 * (BN / 4); idx += NT) {
-      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
-      floatx4 w = {0.f, 0.f, 0.f, 0.f};
-      if (o < g.n_out) w = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
-      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = w;
+    if (t < 16 * (BN / 4)) {
+      const int o = t / (BN / 4), c4 = t - o * (BN / 4);
+      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = pre.wl;
     }
     __syncthreads();
     if (kq < NRB) {  // wave rb: P[row][o] = sum over the tile's columns of h[row][col] * w_last[o][col] for row block rb, one MFMA chain
@@ -1335,6 +1356,9 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, kq = __builtin_amdgcn_readfirstlane(t >> 6);
+  IKF_TSTAMP(10)
+  Skinny16Pre<NCB, NRB> pre;
+  skinny16_prefetch<EPI_RED, NCB, NRB>(g, n0, t, lane, kq, pre);
   floatx4 acc[NRB][NCB];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
@@ -1398,7 +1422,9 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   }
 #undef IK6_LDA
 #undef IK6_LDW
-  skinny16_tail<EPI_RED, NCB, NRB>(g, acc, smem, m0, n0, t, lane, kq);
+  IKF_TSTAMP(11)
+  skinny16_tail<EPI_RED, NCB, NRB>(g, acc, pre, smem, m0, n0, t, lane, kq);
+  IKF_TSTAMP(12)
 }
 
 // one-launch subnet head on 16x16x4 MFMAs: pending coupling of the tile's 16 NRB rows, the whole first Linear + LeakyReLU of those
@@ -1425,8 +1451,11 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   const int M = e.M, D = e.D;
   const int gq = lane >> 4, cl = lane & 15;
 
+  IKF_TSTAMP(20)
   PendingLoads<(R * ROWBUF + NT - 1) / NT, CAP> pl;
   pending_issue_loads<NT, R, false, CAP>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);  // the critical path's loads go first
+  Skinny16Pre<NCB, NRB> pre;
+  skinny16_prefetch<EPI_RED, NCB, NRB>(g, n0, t, lane, kq, pre);
 
   constexpr int WTILE = KKS * KKG * 256;
   const int KT = K / BK;
@@ -1484,7 +1513,9 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
     pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
   }
+  IKF_TSTAMP(21)
   finish_pending_rows<NT, R, CAP>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
+  IKF_TSTAMP(22)
   if (t < R * ROWBUF) {
     if (tn == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
     U[ur * EG_ULD + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v;  // 0 beyond n_in
@@ -1515,6 +1546,7 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
       }
     }
   }
+  IKF_TSTAMP(23)
   floatx4 acc[NRB][NCB];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
@@ -1549,8 +1581,10 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     }
   }
 #undef IK6_LDW
+  IKF_TSTAMP(24)
   __syncthreads();  // every wave is done with the input rows in LDS before the tail reuses the memory
-  skinny16_tail<EPI_RED, NCB, NRB>(g, acc, smem, m0, n0, t, lane, kq);
+  skinny16_tail<EPI_RED, NCB, NRB>(g, acc, pre, smem, m0, n0, t, lane, kq);
+  IKF_TSTAMP(25)
 }
 #undef IKF_MFMA16
 
