@@ -595,6 +595,20 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
   };
   using T_ = std::integral_constant<bool, true>;
 
+  constexpr int WL_F4 = EPI_RED ? (32 * (BN / 4) + NT - 1) / NT : 1;  // float4 of the last Linear's slice per thread
+  float bias_pre[NI];
+  floatx4 wl_pre[WL_F4];
+#define IKF_EPI_PREFETCH                                                                                                   \
+  {                                                                                                                         \
+    _Pragma("unroll") for (int j = 0; j < NI; ++j) bias_pre[j] = g.bias[n0 + wn + j * 32 + (lane & 31)];                     \
+    if constexpr (EPI_RED) {                                                                                                \
+      _Pragma("unroll") for (int i = 0; i < WL_F4; ++i) {                                                                    \
+        const int idx = t + i * NT, o = idx / (BN / 4), c4 = idx - o * (BN / 4);                                             \
+        wl_pre[i] = floatx4{0.f, 0.f, 0.f, 0.f};                                                                             \
+        if (idx < 32 * (BN / 4) && o < g.n_out) wl_pre[i] = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4); \
+      }                                                                                                                     \
+    }                                                                                                                       \
+  }
   // prologue: the (cold) loads of tiles 0, 1 and 2 are issued back to back so their miss latencies overlap
   IKF_TSTAMP(0)
   {
@@ -605,6 +619,9 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     for (int i = 0; i < B_F4; ++i) rb0[i] = IKF_BLD(rsW, b_off[i], 0);
     if (KT > 1) IKF_GLOAD(1, BK)       // tile 1 -> set 1 (stored by iteration 0)
     if (KT > 2) IKF_GLOAD(0, 2 * BK)   // tile 2 -> set 0 (stored by iteration 1)
+    // what the epilogue reads from memory - the bias of this lane's columns and (EPI_RED) this thread's pieces of the last Linear's
+    // slice - is requested here, behind the prologue's operand loads: fetched in the epilogue each costs a round trip there
+    IKF_EPI_PREFETCH
     float* sp0 = smem + lds_t;
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) *reinterpret_cast<floatx4*>(sp0 + i * RS * LDK) = ra0[i];
@@ -634,6 +651,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 #endif
   }
   IKF_TSTAMP(40)
+#undef IKF_EPI_PREFETCH
 #undef IKF_GLOAD
 #undef IKF_BLD
 #undef IKF_LSTORE
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int col = n0 + wn + j * 32 + col_l;
-      const float bv = g.bias[col];
+      const float bv = bias_pre[j];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -676,7 +694,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int cl = wn + j * 32 + col_l;
-      const float bv = g.bias[n0 + cl];
+      const float bv = bias_pre[j];
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -688,11 +706,10 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
         }
       }
     }
-    for (int idx = t; idx < 32 * (BN / 4); idx += NT) {
-      const int o = idx / (BN / 4), c4 = idx - o * (BN / 4);
-      floatx4 v = {0.f, 0.f, 0.f, 0.f};
-      if (o < g.n_out) v = *reinterpret_cast<const floatx4*>(g.w_last + (size_t)o * N + n0 + c4 * 4);
-      *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = v;
+#pragma unroll
+    for (int i = 0; i < WL_F4; ++i) {
+      const int idx = t + i * NT, o = idx / (BN / 4), c4 = idx - o * (BN / 4);
+      if (idx < 32 * (BN / 4)) *reinterpret_cast<floatx4*>(Wl + o * LDT + c4 * 4) = wl_pre[i];
     }
     __syncthreads();
     constexpr int RB = BM / 32;
