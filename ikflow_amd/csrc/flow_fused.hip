@@ -1246,7 +1246,9 @@ constexpr int S16_MAX_RB = 2;    // row blocks per tile: 1 (16-row tiles) or 2 (
 constexpr size_t skinny16_tail_lds() {  // the largest case: two row blocks x two column blocks
   return sizeof(float) * ((size_t)KKS * S16_MAX_RB * 2 * 4 * 64 + (size_t)(S16_MAX_RB * S16_ROWS + 16) * (32 + 4));
 }
-constexpr size_t entry_gemm16_lds() { return sizeof(float) * ((size_t)2 * S16_MAX_RB * S16_ROWS * ROWBUF + S16_MAX_RB * S16_ROWS * EG_ULD); }
+constexpr size_t entry_gemm16_lds() {  // cat, sums, the input rows, and the per-wave slot sums of the pending phase
+  return sizeof(float) * ((size_t)2 * S16_MAX_RB * S16_ROWS * ROWBUF + S16_MAX_RB * S16_ROWS * EG_ULD + 16 + (size_t)KKS * S16_MAX_RB * S16_ROWS * ROWBUF);
+}
 #define IKF_MFMA16(FA, FB, ACC)                                                      \
   {                                                                                  \
     ACC = __builtin_amdgcn_mfma_f32_16x16x4f32(FA.x, FB.x, ACC, 0, 0, 0);            \
@@ -1444,6 +1446,84 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   IKF_TSTAMP(12)
 }
 
+// The pending coupling of R = 16 NRB rows for the 16x16x4 head, by all eight waves.  A memory instruction with 64-bit per-lane addresses
+// costs its SIMD ~70 cycles of issue, and the generic form (pending_issue_loads: one dword load per slot and thread) issues 66 of them in
+// four waves - tools/small_trace.py put the head's first 9.3 k cycles there.  Here wave w takes slots [w S / 8, (w + 1) S / 8): lane l reads
+// 16 bytes - outputs 4 (l % 4) .. + 3 of row l / 4 - per slot through a buffer descriptor (S / 8 <= 8 loads per wave), sums its slots in
+// order and parks the partial in LDS; after a barrier thread (row, o) adds the bias and the eight partials in wave order.  (Another fixed
+// summation order than slot-by-slot: the 16-row kernels agree with the other forms to rounding, as every tile shape does.)
+template <int R>
+struct PendingSlots16 {
+  static constexpr int PASSES = R / 16;
+  floatx4 a[PASSES][8];
+  float xv, bias;
+};
+template <int NT, int R>
+__device__ __forceinline__ void pending16_issue(const PendingCoupling& pc, const float* __restrict__ x_src, int D, int L1, int m0, int M,
+                                                int t, int lane, int wave, PendingSlots16<R>& ps) {
+  const int nl = (pc.which == 1) ? D - L1 : L1;
+  const int spw = (pc.slots + 7) >> 3;  // slots per wave (<= 8: the launcher admits at most 64 slots)
+  const int r16 = lane >> 2, quad = lane & 3;
+  if (pc.P != nullptr) {
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pc.P), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int p = 0; p < PendingSlots16<R>::PASSES; ++p) {
+      const unsigned voff = (unsigned)(((m0 + 16 * p + r16) * IKF_PSTRIDE + 4 * quad) * 4);  // P rows are padded to the tile
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int slot = wave * spw + j;
+        ps.a[p][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (j < spw && slot < pc.slots && 4 * quad < 2 * nl)
+          ps.a[p][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, __builtin_amdgcn_readfirstlane((unsigned)slot * (unsigned)pc.slot_stride * 4u), 0));
+      }
+    }
+  }
+  // one (row, column) item per thread for the state and the bias
+  const int r = t / ROWBUF, d = t % ROWBUF;
+  int gr = m0 + r;
+  gr = gr < M ? gr : M - 1;
+  ps.xv = (t < R * ROWBUF && d < D) ? x_src[(size_t)gr * D + d] : 0.f;
+  ps.bias = (pc.P != nullptr && t < R * ROWBUF && d < 2 * nl) ? pc.b_last[d] : 0.f;
+}
+// `part`: KKS * R * ROWBUF floats of LDS scratch; cat / sums as in finish_pending_rows.  Ends with a barrier.
+template <int NT, int R>
+__device__ __forceinline__ void pending16_finish(const PendingCoupling& pc, const PendingSlots16<R>& ps, int D, int L1, float clamp,
+                                                 float* cat, float* sums, float* part, int t, int lane, int wave) {
+  static_assert(R * ROWBUF <= NT, "one (row, column) item per thread");
+  const int L2 = D - L1;
+  const int nl = (pc.which == 1) ? L2 : L1;
+  const int off = (pc.which == 1) ? L1 : 0;
+  const int r = t / ROWBUF, d = t % ROWBUF;
+  if (pc.P != nullptr) {
+    const int r16 = lane >> 2, quad = lane & 3;
+#pragma unroll
+    for (int p = 0; p < PendingSlots16<R>::PASSES; ++p) {
+      floatx4 sv = ps.a[p][0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) sv += ps.a[p][j];  // slots past this wave's share are zero
+      *reinterpret_cast<floatx4*>(part + ((size_t)wave * R + 16 * p + r16) * ROWBUF + 4 * quad) = sv;
+    }
+    __syncthreads();
+    if (t < R * ROWBUF && d < 2 * nl) {
+      float sv = ps.bias;
+#pragma unroll
+      for (int w = 0; w < KKS; ++w) sv += part[((size_t)w * R + r) * ROWBUF + d];
+      sums[r * ROWBUF + d] = sv;
+    }
+    __syncthreads();
+  }
+  if (t < R * ROWBUF && d < D) {
+    float v = ps.xv;
+    if (pc.P != nullptr && d >= off && d < off + nl) {
+      const int j = d - off;
+      const float s_cl = clamp * (0.636f * atanf(sums[r * ROWBUF + j]));
+      v = (v - sums[r * ROWBUF + nl + j]) * expf(-s_cl);
+    }
+    cat[r * ROWBUF + d] = v;
+  }
+  __syncthreads();
+}
+
 // one-launch subnet head on 16x16x4 MFMAs: pending coupling of the tile's 16 NRB rows, the whole first Linear + LeakyReLU of those
 // rows on the matrix pipe, K loop.  The hidden activation h1 NEVER LEAVES THE REGISTERS: wave kq evaluates exactly the 16-column blocks
 // it will contract - block 8 kt + kq is k slice kq of k tile kt - and the transposed first-Linear product leaves lane l with
@@ -1453,12 +1533,12 @@ template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
 __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
   constexpr int BN = 16 * NCB, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS * NRB;
   constexpr int BPW_MAX = 8;  // first-Linear 16-column blocks per wave at K = 1024
-  constexpr int CAP = NCB == 1 ? 64 : 32;  // partial-sum slots read in one round trip (16-column tiles make twice as many slots)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = g.K, N = g.N;
-  float* cat = smem;               // [R][ROWBUF]   (all three are dead before the tail reuses the memory)
+  float* cat = smem;               // [R][ROWBUF]   (all four are dead before the tail reuses the memory)
   float* sums = cat + R * ROWBUF;
   float* U = sums + R * ROWBUF;    // [R][EG_ULD]
+  float* part = U + R * EG_ULD + 16;  // [KKS][R][ROWBUF] per-wave slot sums (16-byte aligned: R * EG_ULD is a multiple of 16 floats)
   const int tiles_n = N / BN;
   const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * R, n0 = tn * BN;
@@ -1469,8 +1549,8 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   const int gq = lane >> 4, cl = lane & 15;
 
   IKF_TSTAMP(20)
-  PendingLoads<(R * ROWBUF + NT - 1) / NT, CAP> pl;
-  pending_issue_loads<NT, R, false, CAP>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);  // the critical path's loads go first
+  PendingSlots16<R> pl;
+  pending16_issue<NT, R>(e.pend, e.x_src, D, e.L1, m0, M, t, lane, wave, pl);  // the critical path's loads go first
   Skinny16Pre<NCB, NRB> pre;
   skinny16_prefetch<EPI_RED, NCB, NRB>(g, n0, t, lane, kq, pre);
 
@@ -1505,18 +1585,26 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   const int bpw = (K / 16) / NW;  // = K / 128 = the k tiles (launcher: <= BPW_MAX); block i of this wave is k slice kq of k tile i
   float wb[BPW_MAX][4];
   floatx4 bias4[BPW_MAX];
+  {
+    // buffer loads (descriptor + 32-bit lane offset + scalar block offset): a third of the issue cost of 64-bit-address loads
+    const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.w1t), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.b1), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.w1soft), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < BPW_MAX; ++i) {
-    const int cb = i < bpw ? i * NW + wave : 0;
+    for (int i = 0; i < BPW_MAX; ++i) {
+      const int cb = i < bpw ? i * NW + wave : 0;
+      const unsigned cboff = __builtin_amdgcn_readfirstlane((unsigned)(cb * 16 * 4));
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const int k = 4 * s4 + gq;
-      const float v = e.w1t[(size_t)(k < n_in ? k : 0) * e.width + cb * 16 + cl];
-      wb[i][s4] = k < n_in ? v : 0.f;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = 4 * s4 + gq;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsW1, (unsigned)(((k < n_in ? k : 0) * e.width + cl) * 4), cboff, 0));
+        wb[i][s4] = k < n_in ? v : 0.f;
+      }
+      floatx4 bv = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsB1, (unsigned)(4 * gq * 4), cboff, 0));
+      if (e.ps.softflow != 0.0f)
+        bv += e.ps.softflow * __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsS1, (unsigned)(4 * gq * 4), cboff, 0));
+      bias4[i] = bv;
     }
-    floatx4 bv = *reinterpret_cast<const floatx4*>(e.b1 + cb * 16 + 4 * gq);
-    if (e.ps.softflow != 0.0f) bv += e.ps.softflow * *reinterpret_cast<const floatx4*>(e.w1soft + cb * 16 + 4 * gq);
-    bias4[i] = bv;
   }
   // one (row, input column) item per thread: R * ROWBUF <= NT
   static_assert(R * ROWBUF <= NT, "one input element per thread");
@@ -1531,7 +1619,7 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
   }
   IKF_TSTAMP(21)
-  finish_pending_rows<NT, R, CAP>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
+  pending16_finish<NT, R>(e.pend, pl, D, e.L1, e.clamp, cat, sums, part, t, lane, wave);
   IKF_TSTAMP(22)
   if (t < R * ROWBUF) {
     if (tn == 0 && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
@@ -1690,8 +1778,8 @@ bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out) {
   if (cfg == 9 || cfg == 10 || cfg == 11) {  // kSkinny16Cfg: 16 x 32 tiles; kSkinny16x16Cfg: 16 x 16; kSkinny32x32v2Cfg: 32 x 32 on 16x16x4
     const int br = cfg == 11 ? 32 : 16;
     const long long tiles = ((rows + br - 1) / br) * (width / (cfg == 10 ? 16 : 32));
-    return tiles <= 512 && width <= 2048 && width % (2 * KBK) == 0 && (width / 16) % KKS == 0 && (width / 16) / KKS <= 8 &&
-           D <= ROWBUF && n_out <= ROWBUF;  // (its 69 KB of LDS at width 1024 lets two workgroups share a CU)
+    return tiles <= 512 && width / (cfg == 10 ? 16 : 32) <= 64 &&  // <= 64 partial-sum slots: eight per wave in pending16_issue
+           width % (2 * KBK) == 0 && (width / 16) % KKS == 0 && (width / 16) / KKS <= 8 && D <= ROWBUF && n_out <= ROWBUF;  // (its 69 KB of LDS at width 1024 lets two workgroups share a CU)
   }
   if (cfg != 4 && cfg != 6) return false;  // kSkinnyCfg / kSkinny32Cfg
   const int NH = cfg == 4 ? 2 : 1;

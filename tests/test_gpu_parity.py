@@ -1278,7 +1278,8 @@ def test_softflow_scale_and_zero_row_calls():
 def test_small_batch_one_launch_form_equals_two_launches(kw):
     """k_entry_gemm_skinny (entry kernel + first hidden contraction in one launch, <= 256 tiles; the first Linear on the matrix
     pipe, accumulating from the bias with k ascending) against the two-launch form it replaces (ikf_set_gemm_variant 110 =
-    off, 112 = forced for every batch it supports; 111 = the default: taken with the 32x32 tiles only): the f32 MFMA is an fmaf chain, so the two forms must give identical bits; and both match the oracle."""
+    off, 112 = forced for every batch it supports; 111 = the default): the f32 MFMA is an fmaf chain, so with the 32-row tiles the two forms
+    must give identical bits; the 16-row head (<= 128 rows) adds the partial sums in another fixed order and agrees to rounding; all match the oracle."""
     robot, hp, lay, sd = custom_model(seed=12, gain=1.5, **kw)
     s = _solver(robot, hp, sd)
     eng = s.engine(DEV)
@@ -1293,7 +1294,11 @@ def test_small_batch_one_launch_form_equals_two_launches(kw):
         two = s.generate_ik_solutions(P, **kw_n)
         eng.set_gemm_variant(112)
         one = s.generate_ik_solutions(P, **kw_n)
-        assert torch.equal(one, two), f"{kw} n={n}: max diff {(one - two).abs().max().item():.3e}"
+        if n > 128:
+            assert torch.equal(one, two), f"{kw} n={n}: max diff {(one - two).abs().max().item():.3e}"
+        else:  # the 16-row head sums the partial-sum slots per wave first (pending16_issue): another fixed order, equal to rounding
+            assert (one - two).abs().max().item() <= 5e-6, f"{kw} n={n}: max diff {(one - two).abs().max().item():.3e}"
+            assert torch.equal(one, s.generate_ik_solutions(P, **kw_n)), "and the same bits every time"
         err = ((one.cpu() - ref[:n]).abs() / torch.clamp(ref[:n].abs(), min=1.0)).max().item()
         assert err <= FLOW_TOL, f"{kw} n={n}: {err:.2e}"
     # softflow column and the exact path (tile-major pose gather through pose_idx) go through it too
@@ -1306,7 +1311,8 @@ def test_small_batch_one_launch_form_equals_two_launches(kw):
         eng.set_gemm_variant(variant)
         torch.manual_seed(5)
         res.append(s.generate_exact_ik_solutions(poses[:100].to(DEV), pos_error_threshold=0.05, rot_error_threshold=0.5))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # (rounds of <= 128 rows take the 16-row head: seeds equal to rounding, refined to the same solutions)
+    assert torch.equal(res[0][1], res[1][1]) and (res[0][0] - res[1][0]).abs().max().item() <= 1e-3
     eng.set_gemm_variant(111)
 
 
