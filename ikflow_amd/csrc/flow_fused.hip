@@ -1473,7 +1473,7 @@ __device__ __forceinline__ void pending16_issue(const PendingCoupling& pc, const
       for (int j = 0; j < 8; ++j) {
         const int slot = wave * spw + j;
         ps.a[p][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-        if (j < spw && slot < pc.slots && 4 * quad < 2 * nl)
+        if (j < spw && slot < pc.slots && 4 * quad < 2 * nl && m0 + 16 * p + r16 < M)  // (padding rows: nothing to fetch)
           ps.a[p][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, __builtin_amdgcn_readfirstlane((unsigned)slot * (unsigned)pc.slot_stride * 4u), 0));
       }
     }
