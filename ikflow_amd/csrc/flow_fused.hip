@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void skinny16_prefetch(const FusedGemmArgs& g, int n0
 template <bool EPI_RED, int NCB, int NRB>
 __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floatx4 (&acc)[NRB][NCB], const Skinny16Pre<NCB, NRB>& pre,
                                               float* smem, int m0, int n0, int t, int lane, int kq) {
-  constexpr int BN = 16 * NCB, BM = 16 * NRB, LDT = BN + 4, NT = KKS * 64;
+  constexpr int BN = 16 * NCB, BM = 16 * NRB, LDT = BN + 4;
   constexpr int NREG = NRB * NCB * 4;                 // accumulator registers of a lane
   constexpr int RPW = (NREG + KKS - 1) / KKS;         // registers a wave finishes (2 for 2 x 2 blocks, else 1)
   const int N = g.N;
@@ -1365,13 +1365,18 @@ __device__ __forceinline__ void skinny16_tail(const FusedGemmArgs& g, const floa
 // DEEP (K <= 8 k tiles): the whole operand stream is requested up front, tile by tile (sched_barrier keeps that order: tile 0 must not
 // queue behind the rest): a k tile is only 0.1 - 0.4 us of matrix-pipe time per SIMD, two tiles of lead do not cover a round trip.
 constexpr int kDeepTiles = 8;
-template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
-__global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g) {
+// Hand-over hooks of the bodies below.  NoWait: the operands were complete when the launch started (stand-alone kernels).  k_flow_chain16
+// passes an XcdWait (further down): what does not depend on sibling workgroups - weights, biases, poses - is requested BEFORE the wait.
+struct NoWait {
+  __device__ __forceinline__ bool operator()() const { return true; }
+};
+// XL ("XCD-local"): the activations / partial sums / state this body reads were written inside this launch by workgroups on the same XCD:
+// they sit in the shared L2, and the loads carry sc1 so that they miss this CU's L1 (which may hold the buffers' previous contents).
+template <bool EPI_RED, bool DEEP, int NCB, int NRB, bool XL, class Wait>
+__device__ __forceinline__ bool gemm16_body(const FusedGemmArgs& g, int tm, int tn, float* smem, const Wait& wait) {
   constexpr int BM = S16_ROWS * NRB, BN = 16 * NCB, BK = KBK;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // the tail's scratch only
-  const int M = g.M, N = g.N, K = g.K;
-  const int tiles_n = N / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  constexpr int AUX_A = XL ? 16 : 0;
+  const int M = g.M, K = g.K;
   const int m0 = tm * BM, n0 = tn * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, kq = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1397,18 +1402,36 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
     far = far < M ? far : M - 1;
     afrag[rb] = ((unsigned)far * (unsigned)K + kq * KKW + (lane >> 4) * 4) * 4u;
   }
-#define IK6_LDA(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), 0))
+#define IK6_LDA(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsA, off, __builtin_amdgcn_readfirstlane((kt_) * (BK * 4)), AUX_A))
 #define IK6_LDW(off, kt_) __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsW, off, __builtin_amdgcn_readfirstlane((wtile0 + (kt_)) * (WTILE * 4)), 0))
   if constexpr (DEEP) {
     floatx4 aall[kDeepTiles][NRB], wall[kDeepTiles][NCB];
+    if constexpr (XL) {  // the whole W stream first - it does not depend on the siblings - then the wait, then the A stream
 #pragma unroll
-    for (int kt = 0; kt < kDeepTiles; ++kt) {  // unconditional loads (clamped index past the last tile): the compiler counts them
-      const int kc = kt < KT ? kt : KT - 1;
+      for (int kt = 0; kt < kDeepTiles; ++kt) {
+        const int kc = kt < KT ? kt : KT - 1;
 #pragma unroll
-      for (int rb = 0; rb < NRB; ++rb) aall[kt][rb] = IK6_LDA(afrag[rb], kc);
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) wall[kt][cb] = IK6_LDW(woffs[cb], kc);
+        for (int cb = 0; cb < NCB; ++cb) wall[kt][cb] = IK6_LDW(woffs[cb], kc);
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if (!wait()) return false;
+#pragma unroll
+      for (int kt = 0; kt < kDeepTiles; ++kt) {
+        const int kc = kt < KT ? kt : KT - 1;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) aall[kt][rb] = IK6_LDA(afrag[rb], kc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < kDeepTiles; ++kt) {  // unconditional loads (clamped index past the last tile): the compiler counts them
+        const int kc = kt < KT ? kt : KT - 1;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) aall[kt][rb] = IK6_LDA(afrag[rb], kc);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wall[kt][cb] = IK6_LDW(woffs[cb], kc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int kt = 0; kt < kDeepTiles; ++kt) {
@@ -1424,9 +1447,10 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
     floatx4 ac[NRB], an[NRB], wc[NCB], wn[NCB];
     const int k1 = KT > 1 ? 1 : 0;
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) { ac[rb] = IK6_LDA(afrag[rb], 0); an[rb] = IK6_LDA(afrag[rb], k1); }
-#pragma unroll
     for (int cb = 0; cb < NCB; ++cb) { wc[cb] = IK6_LDW(woffs[cb], 0); wn[cb] = IK6_LDW(woffs[cb], k1); }
+    if (!wait()) return false;
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) { ac[rb] = IK6_LDA(afrag[rb], 0); an[rb] = IK6_LDA(afrag[rb], k1); }
     for (int kt = 0; kt < KT; ++kt) {
       const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;
 #pragma unroll
@@ -1444,6 +1468,13 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g
   IKF_TSTAMP(11)
   skinny16_tail<EPI_RED, NCB, NRB>(g, acc, pre, smem, m0, n0, t, lane, kq);
   IKF_TSTAMP(12)
+  return true;
+}
+template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
+__global__ __launch_bounds__(KKS * 64) void k_flow_gemm_skinny16(FusedGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // the tail's scratch only
+  const int tiles_n = g.N / (16 * NCB);
+  gemm16_body<EPI_RED, DEEP, NCB, NRB, false>(g, blockIdx.x / tiles_n, blockIdx.x % tiles_n, smem, NoWait{});
 }
 
 // The pending coupling of R = 16 NRB rows for the 16x16x4 head, by all eight waves.  A memory instruction with 64-bit per-lane addresses
@@ -1458,7 +1489,8 @@ struct PendingSlots16 {
   floatx4 a[PASSES][8];
   float xv, bias;
 };
-template <int NT, int R>
+// SC1: the slots and the state were written inside THIS launch by workgroups of the same XCD (k_flow_chain16): loads that miss the CU's L1.
+template <int NT, int R, bool SC1 = false>
 __device__ __forceinline__ void pending16_issue(const PendingCoupling& pc, const float* __restrict__ x_src, int D, int L1, int m0, int M,
                                                 int t, int lane, int wave, PendingSlots16<R>& ps) {
   const int nl = (pc.which == 1) ? D - L1 : L1;
@@ -1474,7 +1506,7 @@ __device__ __forceinline__ void pending16_issue(const PendingCoupling& pc, const
         const int slot = wave * spw + j;
         ps.a[p][j] = floatx4{0.f, 0.f, 0.f, 0.f};
         if (j < spw && slot < pc.slots && 4 * quad < 2 * nl && m0 + 16 * p + r16 < M)  // (padding rows: nothing to fetch)
-          ps.a[p][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, __builtin_amdgcn_readfirstlane((unsigned)slot * (unsigned)pc.slot_stride * 4u), 0));
+          ps.a[p][j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsP, voff, __builtin_amdgcn_readfirstlane((unsigned)slot * (unsigned)pc.slot_stride * 4u), SC1 ? 16 : 0));
       }
     }
   }
@@ -1482,7 +1514,7 @@ __device__ __forceinline__ void pending16_issue(const PendingCoupling& pc, const
   const int r = t / ROWBUF, d = t % ROWBUF;
   int gr = m0 + r;
   gr = gr < M ? gr : M - 1;
-  ps.xv = (t < R * ROWBUF && d < D) ? x_src[(size_t)gr * D + d] : 0.f;
+  ps.xv = (t < R * ROWBUF && d < D) ? load_partial<SC1>(x_src + (size_t)gr * D + d) : 0.f;
   ps.bias = (pc.P != nullptr && t < R * ROWBUF && d < 2 * nl) ? pc.b_last[d] : 0.f;
 }
 // `part`: KKS * R * ROWBUF floats of LDS scratch; cat / sums as in finish_pending_rows.  Ends with a barrier.
@@ -1529,18 +1561,15 @@ __device__ __forceinline__ void pending16_finish(const PendingCoupling& pc, cons
 // it will contract - block 8 kt + kq is k slice kq of k tile kt - and the transposed first-Linear product leaves lane l with
 // h1[row = 16 rb + l % 16][16 b + 4 (l / 16) + v] in accumulator register v, which is precisely the A fragment (four consecutive k at
 // offset 4 (l / 16) of the slice) the K loop's MFMAs want.  No LDS tile, no barrier between the first Linear and the loop.
-template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
-__global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
+template <bool EPI_RED, bool DEEP, int NCB, int NRB, bool XL, class Wait>
+__device__ __forceinline__ bool entry_gemm16_body(const EntryArgs& e, const FusedGemmArgs& g, int n_in, int tm, int tn, float* smem, const Wait& wait) {
   constexpr int BN = 16 * NCB, BK = KBK, NT = KKS * 64, NW = KKS, R = S16_ROWS * NRB;
   constexpr int BPW_MAX = 8;  // first-Linear 16-column blocks per wave at K = 1024
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int K = g.K, N = g.N;
+  const int K = g.K;
   float* cat = smem;               // [R][ROWBUF]   (all four are dead before the tail reuses the memory)
   float* sums = cat + R * ROWBUF;
   float* U = sums + R * ROWBUF;    // [R][EG_ULD]
   float* part = U + R * EG_ULD + 16;  // [KKS][R][ROWBUF] per-wave slot sums (16-byte aligned: R * EG_ULD is a multiple of 16 floats)
-  const int tiles_n = N / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   const int m0 = tm * R, n0 = tn * BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1550,7 +1579,7 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
 
   IKF_TSTAMP(20)
   PendingSlots16<R> pl;
-  pending16_issue<NT, R>(e.pend, e.x_src, D, e.L1, m0, M, t, lane, wave, pl);  // the critical path's loads go first
+  if constexpr (!XL) pending16_issue<NT, R>(e.pend, e.x_src, D, e.L1, m0, M, t, lane, wave, pl);  // the critical path's loads go first
   Skinny16Pre<NCB, NRB> pre;
   skinny16_prefetch<EPI_RED, NCB, NRB>(g, n0, t, lane, kq, pre);
 
@@ -1617,6 +1646,10 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
     const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
     const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
     pose_v = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
+  }
+  if constexpr (XL) {  // everything above is independent of the sibling workgroups; their partial sums and the state come now
+    if (!wait()) return false;
+    pending16_issue<NT, R, true>(e.pend, e.x_src, D, e.L1, m0, M, t, lane, wave, pl);
   }
   IKF_TSTAMP(21)
   pending16_finish<NT, R>(e.pend, pl, D, e.L1, e.clamp, cat, sums, part, t, lane, wave);
@@ -1690,6 +1723,108 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
   __syncthreads();  // every wave is done with the input rows in LDS before the tail reuses the memory
   skinny16_tail<EPI_RED, NCB, NRB>(g, acc, pre, smem, m0, n0, t, lane, kq);
   IKF_TSTAMP(25)
+  return true;
+}
+template <bool EPI_RED, bool DEEP, int NCB = 2, int NRB = 1>
+__global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, FusedGemmArgs g, int n_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tiles_n = g.N / (16 * NCB);
+  entry_gemm16_body<EPI_RED, DEEP, NCB, NRB, false>(e, g, n_in, blockIdx.x / tiles_n, blockIdx.x % tiles_n, smem, NoWait{});
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// <= 128 rows, the whole subnet chain in ONE launch (r03): 256 persistent workgroups, one per CU; the hand-over between two layers is
+// an arrival counter in the XCD's own L2.
+//   * A kernel boundary costs a dependent chain ~2.4 us plus a cold operand fetch (~1.2 us) - 49 times per call.  A hand-over between
+//     workgroups anywhere on the chip costs more than that (TailSync above: 19 us per round in tools/xcd_sync_probe.cpp's form), but
+//     between workgroups of ONE XCD it is three L2 round trips: stores acknowledged by the shared L2, one atomic add, polls that hit the
+//     L2, operand loads that miss the L1 (sc1) and hit the L2 - 1.9 us per round for 32 workgroups exchanging 8 KB, no fence, no
+//     write-through.  And the next layer's weights are requested BEFORE the wait.
+//   * Decomposition: row tile (16 rows) <-> XCD, column tile (32 columns) <-> one of the XCD's 32 workgroups - exactly the 8 x 32 tiles
+//     of the 16-row kernels at 128 rows, whose bodies run here unchanged (entry_gemm16_body, gemm16_body; XL = sibling-written data is
+//     loaded with sc1).  All exchange (activations, partial sums, the flow state) stays inside a row tile, i.e. inside an XCD.
+//   * Nothing is assumed about placement: a workgroup reads its XCC_ID and takes a ticket from that XCD's counter; (XCC_ID, ticket) is
+//     its (row tile, column tile).  The launcher checks once per handle that the dispatcher hands 32 workgroups to each of 8 XCDs; a
+//     33rd ticket, or a wait that runs out (~1 s), sets the host-visible give-up word and the abort word that ends every other wait.
+//   * The last workgroup to leave zeroes the control words for the next call.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
+
+struct XcdWait {
+  const ChainSync* cs;
+  unsigned* arrive;   // this XCD's counter
+  unsigned target;
+  unsigned* s_ok;     // LDS word
+  __device__ __forceinline__ bool operator()() const {
+    if (threadIdx.x == 0) {
+      unsigned ok = 1, n = 0;
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++n & 63u) == 0 && (n > kChainSpinLimit || __hip_atomic_load(cs->ctl + IKF_CHAIN_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          ok = 0;
+          break;
+        }
+      }
+      if (!ok) {
+        __hip_atomic_store(cs->ctl + IKF_CHAIN_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cs->give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+  }
+};
+// this workgroup's stores of the phase are in the L2; tell the row tile
+__device__ __forceinline__ void xcd_signal(unsigned* arrive) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // (also: every wave is done with the phase's LDS scratch)
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool DEEP>
+__global__ __launch_bounds__(KKS * 64) void k_flow_chain16(const ChainSubnet* __restrict__ tab, int n_sub, ChainCall call, ChainSync cs) {
+  constexpr int NCB = 2, NRB = 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ unsigned s_ticket, s_ok;
+  const int t = threadIdx.x;
+  const unsigned xcd = xcc_id();
+  if (t == 0) s_ticket = xcd < IKF_CHAIN_XCDS ? __hip_atomic_fetch_add(cs.ctl + IKF_CHAIN_TICKET + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffu;
+  __syncthreads();
+  const unsigned ticket = s_ticket;
+  if (ticket >= (unsigned)IKF_CHAIN_PER_XCD) {  // not the placement the launcher verified: nobody may wait for this row tile's full count
+    if (t == 0) {
+      __hip_atomic_store(cs.ctl + IKF_CHAIN_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cs.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  } else if ((int)xcd < cs.row_tiles) {
+    const int tm = (int)xcd, tn = (int)ticket;
+    unsigned* arrive = cs.ctl + IKF_CHAIN_ARRIVE + xcd * 32;
+    unsigned phase = 0;
+    for (int sidx = 0; sidx < n_sub; ++sidx) {
+      EntryArgs e = tab[sidx].e;
+      FusedGemmArgs g0 = tab[sidx].g[0], g1 = tab[sidx].g[1];
+      e.ps = call.ps; e.row0 = call.row0; e.M = call.M;
+      if (sidx == 0) e.x_src = call.x0;
+      g0.M = call.M; g1.M = call.M;
+      // head: pending coupling of the previous subnet (its partial sums: phase `phase`), first Linear, first hidden contraction
+      if (!entry_gemm16_body<false, DEEP, NCB, NRB, true>(e, g0, tab[sidx].n_in, tm, tn, smem,
+                                                          XcdWait{&cs, arrive, (unsigned)IKF_CHAIN_PER_XCD * phase, &s_ok})) break;
+      xcd_signal(arrive);
+      ++phase;
+      // second hidden contraction + the last Linear's partial sums
+      if (!gemm16_body<true, DEEP, NCB, NRB, true>(g1, tm, tn, smem, XcdWait{&cs, arrive, (unsigned)IKF_CHAIN_PER_XCD * phase, &s_ok})) break;
+      xcd_signal(arrive);
+      ++phase;
+    }
+  }
+  // the last workgroup out resets the control words (every other one is past its last wait)
+  __syncthreads();
+  if (t == 0) {
+    const unsigned d = __hip_atomic_fetch_add(cs.ctl + IKF_CHAIN_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == gridDim.x - 1)
+      for (int i = 0; i < IKF_CHAIN_CTL_WORDS; ++i) __hip_atomic_store(cs.ctl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 #undef IKF_MFMA16
 
@@ -1770,6 +1905,35 @@ static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a
   if (hipError_t err = ensure_dynamic_lds(kern, smem, lds_ok); err != hipSuccess) return err;
   const long long grid = (((long long)a.M + S16_ROWS * NRB - 1) / (S16_ROWS * NRB)) * (a.N / (16 * NCB));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(KKS * 64), smem, s, e, a, n_in);
+  return hipGetLastError();
+}
+
+constexpr size_t kChainLds = 84 * 1024;  // more than half a CU's LDS: one chain workgroup per CU
+bool flow_chain16_ok(long long rows, int width, int D, int n_out, int n_hidden) {
+  return rows >= 1 && rows <= (long long)S16_ROWS * IKF_CHAIN_XCDS && n_hidden == 3 && width == 32 * IKF_CHAIN_PER_XCD &&
+         entry_gemm_ok(fused_skinny16_cfg(), rows, width, D, n_out);
+}
+__global__ __launch_bounds__(KKS * 64) void k_xcd_census(unsigned* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+hipError_t launch_xcd_census(unsigned* d_out, hipStream_t s) {
+  static bool lds_ok[64] = {};
+  if (hipError_t err = ensure_dynamic_lds(k_xcd_census, kChainLds, lds_ok); err != hipSuccess) return err;
+  hipLaunchKernelGGL(k_xcd_census, dim3(IKF_CHAIN_XCDS * IKF_CHAIN_PER_XCD), dim3(KKS * 64), kChainLds, s, d_out);
+  return hipGetLastError();
+}
+hipError_t launch_flow_chain16(const ChainSubnet* d_tab, int n_sub, const ChainCall& call, const ChainSync& cs, int K, hipStream_t s) {
+  if (call.M <= 0) return hipSuccess;
+  static_assert(kChainLds >= entry_gemm16_lds() && kChainLds >= skinny16_tail_lds(), "the chain's bodies fit");
+  static bool lds_ok[64] = {};
+  const dim3 grid(IKF_CHAIN_XCDS * IKF_CHAIN_PER_XCD), block(KKS * 64);
+  if (K <= kDeepTiles * KBK) {
+    if (hipError_t err = ensure_dynamic_lds(k_flow_chain16<true>, kChainLds, lds_ok); err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_flow_chain16<true>, grid, block, kChainLds, s, d_tab, n_sub, call, cs);
+  } else {
+    if (hipError_t err = ensure_dynamic_lds(k_flow_chain16<false>, kChainLds, lds_ok); err != hipSuccess) return err;
+    hipLaunchKernelGGL(k_flow_chain16<false>, grid, block, kChainLds, s, d_tab, n_sub, call, cs);
+  }
   return hipGetLastError();
 }
 

@@ -69,6 +69,17 @@ struct ikf_model {
   // write-through, 1.831 -> 1.796 at 2048 and 0.721 -> 0.706 at 512 with the entry kernel's too; the entry kernel's 16-byte stores do
   // not pay at 4096 rows).  bit 0 contractions, bit 1 entry kernel; -1 = by batch size (contractions always, entry kernel <= 2048 rows)
   int wt_stores = -1;
+  // <= 128 rows: the whole subnet chain in one launch, hand-over inside each XCD (k_flow_chain16, flow_fused.hip).  OFF by default:
+  // bit-identical to the per-layer launches but slower (r03: 0.422 against 0.365 ms per call at 128 rows, 0.362 against 0.271 at 1 row) -
+  // a hand-over inside an XCD needs the ROWS partitioned over the XCDs, so every XCD's L2 pulls the whole 4.2 MB weight matrix of every
+  // layer (8 x the traffic of the per-layer launches, whose column tiles are spread over the XCDs), and small batches are bound by
+  // exactly that stream.  Kept as the tested, priced answer to "XCD-local synchronisation".
+  //   chain_mode: 0 off, 1 on (ikf_set_gemm_variant 170 / 171); chain_census: -1 not yet taken, 0 the dispatcher does not hand 32
+  //   workgroups to each of 8 XCDs on this device (the chain is never used), 1 verified
+  int chain_mode = 0, chain_census = -1;
+  ChainSubnet* d_chain_tab = nullptr;  // [2 nb_nodes] per-subnet arguments, rebuilt when the weights or the scratch change
+  bool chain_tab_valid = false;
+  unsigned* d_chain_ctl = nullptr;     // [IKF_CHAIN_CTL_WORDS], zero between calls (the launch's last workgroup re-zeroes it)
   unsigned* d_arrive = nullptr;  // [kArriveWords] row-tile arrival counters of the fused tail (zeroed by every call's first entry kernel)
   int* h_give_up = nullptr;      // pinned, device-visible: set by a workgroup whose in-launch wait ran out
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
@@ -190,6 +201,7 @@ static void free_scratch(ikf_model* m) {
   if (m->pbuf) (void)hipFree(m->pbuf);
   m->xbuf = m->hA = m->hB = m->xbuf2 = m->pbuf = nullptr;
   m->chunk_rows = 0;
+  m->chain_tab_valid = false;  // (the table holds these pointers)
 }
 static void free_exact(ikf_model* m) {
   if (m->ex_q) (void)hipFree(m->ex_q);
@@ -261,6 +273,9 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   if (e == hipSuccess) e = hipMemset(m->d_arrive, 0, sizeof(unsigned) * kArriveWords);
   if (e == hipSuccess) e = hipHostMalloc(&m->h_give_up, sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) *m->h_give_up = 0;
+  if (e == hipSuccess) e = hipMalloc(&m->d_chain_ctl, sizeof(unsigned) * IKF_CHAIN_CTL_WORDS);
+  if (e == hipSuccess) e = hipMemset(m->d_chain_ctl, 0, sizeof(unsigned) * IKF_CHAIN_CTL_WORDS);
+  if (e == hipSuccess) e = hipMalloc(&m->d_chain_tab, sizeof(ChainSubnet) * 2 * (size_t)desc->nb_nodes);
   if (e != hipSuccess) {
     ikf_destroy(m);
     return fail(IKF_ERR_HIP, std::string("ikf_create: allocation failed: ") + hipGetErrorString(e));
@@ -289,6 +304,8 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->h_split_flag) (void)hipHostFree(m->h_split_flag);
   if (m->d_arrive) (void)hipFree(m->d_arrive);
   if (m->h_give_up) (void)hipHostFree(m->h_give_up);
+  if (m->d_chain_ctl) (void)hipFree(m->d_chain_ctl);
+  if (m->d_chain_tab) (void)hipFree(m->d_chain_tab);
   for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
   if (m->tail_event) (void)hipEventDestroy(m->tail_event);
   delete m;
@@ -542,6 +559,7 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
   // The f32 images first and unconditionally: whatever happens to the f16x3 images below, every batch size of the f32 path
   // must see the NEW weights (the <= 512-row kernels read the fragment-major copy).
   m->loaded = false;
+  m->chain_tab_valid = false;  // (the chain's argument table points into the weight arenas)
   ikf_status fst = build_frag_weights(m);
   if (fst != IKF_OK) return fst;
   m->loaded = true;
@@ -636,6 +654,10 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->wt_stores = variant == 134 ? -1 : variant - 130;
     return IKF_OK;
   }
+  if (variant == 170 || variant == 171) {  // <= 128 rows: the whole subnet chain in one launch (XCD-local hand-over): off / on
+    m->chain_mode = variant - 170;
+    return IKF_OK;
+  }
   if (variant == 120 || variant == 121) {  // next subnet's entry phase in the tail of the last hidden contraction: off / on
     m->fuse_tail = variant - 120;
     return IKF_OK;
@@ -706,11 +728,122 @@ static bool fused_ok(const ikf_model* m) {
 
 // three kernels per subnet (flow_fused.hip): entry (pending coupling + first Linear), hidden contraction(s), the last
 // of which reduces the last Linear to partial sums; one finalize kernel after the last subnet
+// ---- <= 128 rows: the subnet chain in one launch (k_flow_chain16) + the finalize kernel
+// One-time check per handle that a chain-shaped launch gets 32 workgroups on each of 8 XCDs (the kernel would notice and give up;
+// this keeps a device in another partition mode, or with masked CUs, from ever trying).  Synchronous: first use only.
+static ikf_status chain_census(ikf_model* m, hipStream_t s) {
+  if (m->chain_census >= 0) return IKF_OK;
+  m->chain_census = 0;
+  hipDeviceProp_t prop{};
+  IKF_HIP(hipGetDeviceProperties(&prop, m->device));
+  if (prop.multiProcessorCount != IKF_CHAIN_XCDS * IKF_CHAIN_PER_XCD) return IKF_OK;
+  unsigned* d_out = nullptr;
+  IKF_HIP(hipMalloc(&d_out, sizeof(unsigned) * 256));
+  hipError_t e = launch_xcd_census(d_out, s);
+  unsigned h[256];
+  if (e == hipSuccess) e = hipMemcpyAsync(h, d_out, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(d_out);
+  IKF_HIP(e);
+  int per[16] = {};
+  for (int b = 0; b < 256; ++b) per[h[b] & 15]++;
+  bool ok = true;
+  for (int x = 0; x < 16; ++x) ok = ok && per[x] == (x < IKF_CHAIN_XCDS ? IKF_CHAIN_PER_XCD : 0);
+  m->chain_census = ok ? 1 : 0;
+  return IKF_OK;
+}
+static bool chain_usable(const ikf_model* m, long long nr) {
+  const FlowDims& d = m->dims;
+  if (m->chain_mode == 0 || m->chain_census == 0 || m->tile_cfg >= 0 || m->fuse_entry != 1 || m->fuse_tail != 0 || m->prof_on) return false;
+  if ((m->tune & (IKF_TUNE_ROWS16 | IKF_TUNE_DEEP16)) != (IKF_TUNE_ROWS16 | IKF_TUNE_DEEP16)) return false;
+  if (!flow_chain16_ok(nr, d.width, d.D, 2 * (d.L1 > d.L2 ? d.L1 : d.L2), d.n_hidden)) return false;
+  for (int si = 0; si < 2 * m->desc.nb_nodes; ++si)
+    if (m->subnets[si].n_x + d.n_pose > 15) return false;
+  return true;
+}
+static ikf_status chain_table(ikf_model* m) {
+  if (m->chain_tab_valid) return IKF_OK;
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes;
+  const long long rows_pad = m->chunk_rows;
+  std::vector<ChainSubnet> tab((size_t)2 * NB);
+  float* xb[2] = {m->xbuf, m->xbuf2};
+  PendingCoupling pend{};
+  const float* x_src = nullptr;
+  for (int sidx = 0; sidx < 2 * NB; ++sidx) {
+    const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
+    const int si = 2 * b + which - 1;
+    const SubnetWeights& w = m->subnets[si];
+    if (frag_image(m, si, 0) == nullptr || frag_image(m, si, 1) == nullptr) return fail(IKF_ERR_HIP, "chain_table: no fragment image");
+    ChainSubnet& c = tab[sidx];
+    memset(&c, 0, sizeof(c));
+    EntryArgs& e = c.e;
+    e.pend = pend;
+    e.x_src = x_src; e.x_dst = xb[sidx & 1];
+    e.D = d.D; e.L1 = d.L1; e.clamp = d.clamp;
+    e.x_off = (which == 1) ? 0 : d.L1; e.n_x = w.n_x;
+    e.w1t = w.w_first_t; e.w1soft = w.w_soft; e.b1 = w.b_first;
+    e.width = d.width; e.slope = d.slope; e.h_out = m->hA;
+    c.n_in = w.n_x + d.n_pose;
+    for (int l = 0; l < 2; ++l) {
+      FusedGemmArgs& g = c.g[l];
+      g.N = d.width; g.K = d.width; g.slope = d.slope; g.tune = m->tune;
+      g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
+      g.W = w.w_mid[l]; g.bias = w.b_mid[l]; g.Wf = frag_image(m, si, l);
+    }
+    c.g[0].A = m->hA; c.g[0].C = m->hB;   // (the head keeps the first Linear's output in registers: A is unused)
+    c.g[1].A = m->hB; c.g[1].C = nullptr;
+    pend = PendingCoupling{};
+    pend.P = m->pbuf;
+    pend.b_last = w.b_last;
+    pend.perm_inv = m->d_perm_inv + (size_t)b * d.D;
+    pend.slot_stride = rows_pad * IKF_PSTRIDE;
+    pend.slots = fused_slots(fused_skinny16_cfg(), d.width);
+    pend.which = which;
+    pend.n_out = w.n_out;
+    x_src = e.x_dst;
+  }
+  IKF_HIP(hipMemcpy(m->d_chain_tab, tab.data(), sizeof(ChainSubnet) * tab.size(), hipMemcpyHostToDevice));
+  m->chain_tab_valid = true;
+  return IKF_OK;
+}
+static ikf_status run_flow_chunk_chain(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r0, long long nr,
+                                       int clamp_limits, float* d_q_out, hipStream_t s) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes;
+  ikf_status st = chain_table(m);
+  if (st != IKF_OK) return st;
+  ChainCall call{};
+  call.ps = ps; call.x0 = d_latent + (size_t)r0 * d.D; call.row0 = r0; call.M = (int)nr;
+  ChainSync cs{};
+  cs.ctl = m->d_chain_ctl; cs.give_up = m->h_give_up; cs.row_tiles = (int)((nr + 15) / 16);
+  IKF_HIP(launch_flow_chain16(m->d_chain_tab, 2 * NB, call, cs, d.width, s));
+  const SubnetWeights& w = m->subnets[1];  // the last subnet in execution order: block 0, s2
+  PendingCoupling pend{};
+  pend.P = m->pbuf; pend.b_last = w.b_last; pend.perm_inv = m->d_perm_inv;
+  pend.slot_stride = m->chunk_rows * IKF_PSTRIDE; pend.slots = fused_slots(fused_skinny16_cfg(), d.width);
+  pend.which = 2; pend.n_out = w.n_out;
+  float* xb[2] = {m->xbuf, m->xbuf2};
+  FinalizeArgs f{};
+  f.pend = pend; f.x_src = xb[(2 * NB - 1) & 1]; f.M = (int)nr; f.D = d.D; f.L1 = d.L1; f.ndof = d.ndof; f.clamp = d.clamp;
+  f.M_inv = m->d_Minv; f.b_lin = m->d_blin; f.lo = chain_lo(m); f.hi = chain_hi(m);
+  f.clamp_limits = clamp_limits; f.sigmoid = m->desc.sigmoid_on_output ? 1 : 0; f.q_out = d_q_out + (size_t)r0 * d.ndof;
+  IKF_HIP(launch_flow_finalize(f, s));
+  return IKF_OK;
+}
+
 static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r0,
                                        long long nr, int clamp_limits, float* d_q_out, hipStream_t s) {
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
+  if (chain_usable(m, nr)) {
+    if (m->chain_census < 0) {
+      ikf_status cst = chain_census(m, s);
+      if (cst != IKF_OK) return cst;
+    }
+    if (m->chain_census == 1) return run_flow_chunk_chain(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s);
+  }
   const int cfg = (m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width, m->tune);
   // f16x3 mode: its own tile choice; the partial-sum slots follow the kernel that writes them
   // (f16x3 mode, batches that pick the 16-row f32 tiles - <= 128 rows: the exact-f32 kernels are the faster ones there since round 3,
@@ -889,6 +1022,8 @@ static ikf_status check_ready(ikf_model* m, const char* fn) {
     // switched off for this handle and every later call uses the plain launch boundary.
     *m->h_give_up = 0;
     m->fuse_tail = 0;
+    m->chain_mode = 0;
+    if (m->d_chain_ctl) (void)hipMemset(m->d_chain_ctl, 0, sizeof(unsigned) * IKF_CHAIN_CTL_WORDS);
     return fail(IKF_ERR_HIP, std::string(fn) + ": an in-launch hand-over of a PREVIOUS call timed out - that call's results are invalid; "
                                                "the in-launch hand-over is now disabled for this handle, repeat the call");
   }

@@ -135,6 +135,34 @@ struct FusedGemmArgs {
   float* P_out;         // [slots][rows_pad][IKF_PSTRIDE]
   long long p_slot_stride;
 };
+// The whole subnet chain of a call in one launch for <= 128 rows (k_flow_chain16, flow_fused.hip): 256 persistent workgroups, row tile <->
+// XCD, hand-over between layers through an arrival counter in the XCD's L2.
+constexpr int IKF_CHAIN_XCDS = 8, IKF_CHAIN_PER_XCD = 32;     // the placement the launcher verifies (launch_xcd_census)
+constexpr int IKF_CHAIN_TICKET = 0;                           // ctl[TICKET + 32 x]: workgroups of XCD x so far (one 128-byte line per XCD)
+constexpr int IKF_CHAIN_ARRIVE = 32 * IKF_CHAIN_XCDS;         // ctl[ARRIVE + 32 x]: phase arrivals of row tile x
+constexpr int IKF_CHAIN_ABORT = 64 * IKF_CHAIN_XCDS;          // non-zero: a wait ran out somewhere, every wait ends
+constexpr int IKF_CHAIN_DONE = IKF_CHAIN_ABORT + 1;           // workgroups that left; the last one zeroes ctl[]
+constexpr int IKF_CHAIN_CTL_WORDS = IKF_CHAIN_DONE + 1;
+constexpr unsigned kChainSpinLimit = 1u << 22;                // polls (s_sleep 1 + one L2 load each): about a second
+struct ChainSubnet {       // device table, execution order; built once per (weights, scratch) - nothing in it depends on the call
+  EntryArgs e;             // pend.P == nullptr for the first subnet; ps / row0 / M / (first subnet) x_src come from ChainCall
+  FusedGemmArgs g[2];      // the two hidden contractions (g[0] runs in the head; g[1] ends in the last Linear's partial sums)
+  int n_in;
+};
+struct ChainCall {         // what changes from call to call
+  PoseSource ps;
+  const float* x0;         // state rows of the first subnet (the caller's latent, already offset to the chunk)
+  long long row0;
+  int M;
+};
+struct ChainSync {
+  unsigned* ctl;           // IKF_CHAIN_CTL_WORDS words, zero between calls
+  int* give_up;            // host-visible word (see TailSync)
+  int row_tiles;           // XCDs x >= row_tiles have nothing to do
+};
+bool flow_chain16_ok(long long rows, int width, int D, int n_out, int n_hidden);
+hipError_t launch_flow_chain16(const ChainSubnet* d_tab, int n_sub, const ChainCall& call, const ChainSync& cs, int K, hipStream_t s);
+hipError_t launch_xcd_census(unsigned* d_out /* [256] */, hipStream_t s);  // out[b] = XCC_ID of workgroup b of a chain-shaped launch
 struct FinalizeArgs {
   PendingCoupling pend;
   const float* x_src;  // [M][D]

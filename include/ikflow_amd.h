@@ -252,6 +252,7 @@ const char* ikf_dominant_kernel_name(void);
  *   152 / 153        the 16-row kernels request their whole operand stream up front: off / on (default)
  *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced
  *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced
+ *   170 / 171        <= 128 rows: the whole subnet chain in one launch, hand-over between layers inside each XCD: off (default) / on
  * Returns IKF_ERR_BAD_ARGUMENT if unknown. */
 ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 

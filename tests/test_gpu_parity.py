@@ -1370,6 +1370,57 @@ def test_in_launch_entry_phase_equals_entry_launches(kw):
 
 
 @pytest.mark.parametrize("kw", [
+    dict(nb_nodes=3, dim=7, n_hidden=3, width=1024),                              # the released shape
+    dict(nb_nodes=2, dim=8, n_hidden=3, width=1024, robot_name="fetch"),          # prismatic joint, softflow column
+    dict(nb_nodes=3, dim=7, n_hidden=3, width=1024, softflow=False, sigmoid=True),
+    dict(nb_nodes=2, dim=9, n_hidden=2, width=256),                               # not a shape the chain takes: the switch must be a no-op
+])
+def test_one_launch_chain_equals_per_layer_launches(kw):
+    """The whole subnet chain of a <= 128-row call in ONE launch (k_flow_chain16, ikf_set_gemm_variant 171 - an opt-in: it measured slower,
+    DESIGN.md section 4): 256 persistent workgroups, (XCC_ID, ticket) = (row tile, column tile), arrival counters in the XCD's L2 between the
+    layers, sibling-written operands read past the L1.  Against the per-layer launches on the same 16 x 32 tiles (170 + 158): the same bodies
+    in the same order, so identical bits - at every row-tile count 1 .. 8, ragged last tiles, repeated (the last workgroup out re-zeroes the
+    control words), interleaved with batches the chain does not take, single-pose form, exact path; and it matches the oracle."""
+    robot, hp, lay, sd = custom_model(seed=77, gain=1.5, **kw)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n_max = 300
+    _, poses = reachable_poses(robot, n_max, 131)
+    lat = latents(n_max, lay.dim, 132)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
+    eng.set_gemm_variant(158)  # 16 x 32 tiles for every batch of <= 128 rows, as the chain uses
+    for n in (1, 2, 15, 16, 17, 33, 64, 100, 127, 128, 129, 300, 5):
+        P, L = poses[:n].to(DEV), lat[:n].to(DEV)
+        kw_n = dict(n=(1 if n == 1 else None), latent=L, clamp_to_joint_limits=False)
+        eng.set_gemm_variant(170)
+        per_layer = s.generate_ik_solutions(P, **kw_n)
+        eng.set_gemm_variant(171)
+        chain = s.generate_ik_solutions(P, **kw_n)
+        again = s.generate_ik_solutions(P, **kw_n)
+        assert torch.equal(chain, per_layer), f"{kw} n={n}: max diff {(chain - per_layer).abs().max().item():.3e}"
+        assert torch.equal(chain, again)
+        err = ((chain.cpu() - ref[:n]).abs() / torch.clamp(ref[:n].abs(), min=1.0)).max().item()
+        assert err <= FLOW_TOL, f"{kw} n={n}: {err:.2e}"
+    one = s.generate_ik_solutions(poses[0].to(DEV), n=100, latent=lat[:100].to(DEV))  # pose broadcast
+    eng.set_gemm_variant(170)
+    assert torch.equal(one, s.generate_ik_solutions(poses[0].to(DEV), n=100, latent=lat[:100].to(DEV)))
+    if lay.dim_cond == 8:  # softflow column
+        eng.set_gemm_variant(171)
+        cond = torch.cat([poses[:100], torch.full((100, 1), 0.4)], dim=1)
+        got = eng.generate_approx(poses[:100].to(DEV), lat[:100].to(DEV), False, softflow_scale=0.4).cpu()
+        assert (got - fo.run_inference_torch(sd, lay, robot, lat[:100], cond, False)).abs().max().item() <= 10 * FLOW_TOL
+    res = []
+    for variant in (170, 171):  # exact path: 60 poses, rounds of 60 / <= 180 / <= 600 rows (pose gather through pose_idx, row offsets)
+        eng.set_gemm_variant(variant)
+        torch.manual_seed(5)
+        torch.cuda.manual_seed(5)
+        res.append(s.generate_exact_ik_solutions(poses[:60].to(DEV), pos_error_threshold=0.05, rot_error_threshold=0.5))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    eng.set_gemm_variant(170)
+    eng.set_gemm_variant(159)
+
+
+@pytest.mark.parametrize("kw", [
     dict(nb_nodes=3, dim=7, n_hidden=3, width=1024),                          # the released shape
     dict(nb_nodes=2, dim=9, n_hidden=2, width=256),                           # TINY's: head and last contraction are one launch
     dict(nb_nodes=2, dim=10, n_hidden=4, width=768, robot_name="fetch_arm"),  # a middle contraction (stores its activation)

@@ -13,6 +13,8 @@ robot = Panda(); hp = hparams_for("panda__full__lp191_5.25m"); lay = layout_from
 s = IKFlowSolver(hp, robot); s.load_state_dict_tensors(random_state_dict(lay, robot, 0)); eng = s.engine(dev)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+for code in (sys.argv[2].split(",") if len(sys.argv) > 2 else []):  # engine variants, e.g. 171 = the one-launch chain (stamps of its LAST subnet)
+    eng.set_gemm_variant(int(code))
 nb = 4096
 buf = torch.zeros(nb * 64, dtype=torch.int64, device=dev)
 poses = torch.randn(B, 7, device=dev); poses[:, 3:] /= poses[:, 3:].norm(dim=1, keepdim=True)

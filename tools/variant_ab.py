@@ -12,7 +12,7 @@ s = IKFlowSolver(hp, robot); s.load_state_dict_tensors(random_state_dict(lay, ro
 codes = [[int(y) for y in x.split("+")] for x in sys.argv[1].split(",")]  # "160+110" = both codes set
 sizes = [int(x) for x in sys.argv[2].split(",")]
 def t(B, variant, steps):
-    for c in (100, 111, 134, 120, 151, 153, 159, 162):  # defaults
+    for c in (100, 111, 134, 120, 151, 153, 159, 162, 170):  # defaults
         eng.set_gemm_variant(c)
     for c in variant:
         eng.set_gemm_variant(c)
