@@ -684,9 +684,8 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
       }
     }
   } else {
-    // ---- last Linear restricted to this tile's columns:  P^T[o][row] = sum_col W4[o][col] * h[row][col]
-    // h tile -> LDS T[BM][LDT]; W4 slice -> LDS Wl[32][LDT] (rows >= n_out zero); then the same K-contiguous fragment
-    // scheme as the main loop with "A" = Wl (32 x BN) and "B" = T (BM x BN): wave w owns row block w % 4 and the
+    // ---- last Linear restricted to this tile's columns:  P[row][o] = sum_col h[row][col] * W4[o][col]
+    // h tile -> LDS T[BM][LDT]; W4 slice -> LDS Wl[32][LDT] (rows >= n_out zero); wave w owns row block w % 4 and the
     // column half w / 4 (its own partial-sum slot).
     __syncthreads();  // every wave is done reading the last stage
     float* T = smem;
@@ -714,34 +713,38 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     __syncthreads();
     constexpr int RB = BM / 32;
     constexpr int CW = 64;  // columns per slot
+    // On v_mfma_f32_16x16x4_f32: n_out <= 16, so the 32x32x2 shape would spend half of its 4096 matrix-pipe cycles per tile on zero rows
+    // of W4 (r03, tools/gemm_trace.py: 7.3 k cycles of epilogue behind a K loop that runs at 97 % of the pipe).  "A" = 16 rows of h,
+    // "B" = W4 (j = output), four consecutive columns per lane at 4 (lane / 16) of a 16-column group, component c -> MFMA c.
     for (int job = wave; job < RB * FKH; job += NT / 64) {  // wave-uniform: (row block, 64-column slot) jobs over the waves
       const int rb = job % RB, kh = job / RB;
-      floatx16 pacc;
+      typedef float floatx4_ __attribute__((ext_vector_type(4)));
+      floatx4_ pacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      const int gq = lane >> 4, l16 = lane & 15;
+      const float* pa = T + (rb * 32 + l16) * LDT + kh * CW + gq * 4;
+      const float* pb = Wl + l16 * LDT + kh * CW + gq * 4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
-      const float* pa = Wl + (lane & 31) * LDT + kh * CW + (lane >> 5) * 4;
-      const float* pb = T + (rb * 32 + (lane & 31)) * LDT + kh * CW + (lane >> 5) * 4;
+      for (int ks = 0; ks < CW / 16; ++ks) {
+        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 16);
 #pragma unroll
-      for (int ks = 0; ks < CW / 8; ++ks) {
-        const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + ks * 8);
-        const floatx4 b4 = *reinterpret_cast<const floatx4*>(pb + ks * 8);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, pacc, 0, 0, 0);
+        for (int sb = 0; sb < 2; ++sb) {
+          const floatx4 a4 = *reinterpret_cast<const floatx4*>(pa + sb * 16 * LDT + ks * 16);
+          pacc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, pacc[sb], 0, 0, 0);
+          pacc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, pacc[sb], 0, 0, 0);
+          pacc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, pacc[sb], 0, 0, 0);
+          pacc[sb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, pacc[sb], 0, 0, 0);
+        }
       }
-      // pacc[reg] = P^T[o][row], o = (reg&3) + 8*(reg>>2) + 4*(lane>>5), row = lane&31; o < 16 lives in regs 0..7:
-      // registers 0..3 are outputs row_h .. row_h+3, registers 4..7 outputs 8+row_h .. 8+row_h+3 - two 16-byte stores
-      const size_t pidx = (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + (lane & 31)) * IKF_PSTRIDE + row_h;
-      const floatx4 p_lo = {pacc[0], pacc[1], pacc[2], pacc[3]}, p_hi = {pacc[4], pacc[5], pacc[6], pacc[7]};
-      if constexpr (FUSE) {
-        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(g.P_out, 0, 0x7fffffff, 0x00020000);
-        store16_wt(rsP, (unsigned)(pidx * 4), p_lo);
-        store16_wt(rsP, (unsigned)((pidx + 8) * 4), p_hi);
-      } else {
-        *reinterpret_cast<floatx4*>(g.P_out + pidx) = p_lo;
-        *reinterpret_cast<floatx4*>(g.P_out + pidx + 8) = p_hi;
-      }
+      // pacc[sb][v] = P[row = 32 rb + 16 sb + 4 (lane / 16) + v][o = lane % 16]: 64-byte runs per row
+      float* pout = g.P_out + (size_t)(n0 / CW + kh) * g.p_slot_stride + (size_t)(m0 + rb * 32 + 4 * gq) * IKF_PSTRIDE + l16;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float* dst = pout + (size_t)(16 * sb + v) * IKF_PSTRIDE;
+          if constexpr (FUSE) __hip_atomic_store(dst, pacc[sb][v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+          else *dst = pacc[sb][v];
+        }
     }
     if constexpr (FUSE) {
       static_assert(3 * STAGE >= (int)tail_lds_floats(BM, BN), "the tail's LDS fits in the stage area");
