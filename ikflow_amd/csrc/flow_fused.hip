@@ -998,24 +998,27 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
   // The loop body is branch-free: prefetches past the last tile re-read the last tile (clamped index) and the extra
   // LDS image is never consumed.  With conditional loads the compiler cannot count outstanding loads across the back
   // edge and falls back to s_waitcnt vmcnt(0) in front of the MFMAs, i.e. a full memory round trip per iteration.
-#define IKK_WLOAD(WC, kk) WC[kk] = IKK_LDW(kk, k2);
+#define IKK_WLOAD(WC, kk) if (!(IKK_ABL & 8)) WC[kk] = IKK_LDW(kk, k2);
   // One barrier per tile, two LDS stages: A tile kt+1 is written into the other stage at the top of iteration kt (all
   // its readers - iteration kt-1 - finished before the barrier of iteration kt-1) and its first fragment is fetched
   // behind the barrier.  WC holds the W fragments of tile kt, WN those of tile kt+1; each WC[kk] is refilled with tile
   // kt+2 as soon as its MFMA group has issued.  The loop is unrolled by two so both the stage index and the register
   // set are compile-time: every LDS address is an immediate offset.  Four waves share a SIMD, so while one of them
   // issues its loads / LDS traffic the other three keep the matrix pipe fed.
+#ifndef IKK_ABL   // probes only (tools/gemm_probe.hip): ablations of the loop's memory side - bit 0 no barrier, 1 no LDS store, 2 no A load, 3 no W load
+#define IKK_ABL 0
+#endif
 #define IKK_ITER(WC, WN, CUR, NXT)                                                        \
   {                                                                                       \
     const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;                                       \
     IKK_FRAG(fa1, CUR, 1)                                                                 \
-    _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; \
-    _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k2);               \
+    if (!(IKK_ABL & 2)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; } \
+    if (!(IKK_ABL & 4)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k2); }  \
     IKK_PIN                                                                               \
     IKK_MFMA(fa0, WC[0])                                                                  \
     IKK_WLOAD(WC, 0)                                                                      \
     IKK_PIN                                                                               \
-    __syncthreads();                                                                      \
+    if (!(IKK_ABL & 1)) __syncthreads();                                                  \
     IKK_FRAG(fa0, NXT, 0)                                                                 \
     IKK_PIN                                                                               \
     IKK_MFMA(fa1, WC[1])                                                                  \
@@ -1025,7 +1028,7 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
     ++kt;                                                                                 \
   }
 #define IKK_PIN __builtin_amdgcn_sched_barrier(0);  // keep the hand-placed load / LDS / MFMA order
-#ifdef IKF_TRACE
+#if defined(IKF_TRACE) && !defined(IKK_NO_STAGE_STAMP)   // (a stamp per stage costs wave 0 - and behind the barrier everyone - ~240 cycles)
 #define IKK_STAMP if (kt < 32) IKF_TSTAMP(2 + kt)
 #else
 #define IKK_STAMP
