@@ -37,7 +37,6 @@ namespace ikf {
 #define IKF_TSTAMP(i)
 #endif
 
-constexpr int FBK = 32;
 constexpr int ROWBUF = 16;  // floats per row in the small per-row LDS arrays (>= D, >= n_out)
 
 // Tile configurations of the hidden contraction, chosen by the row count so that the launch has >= 256 workgroups
@@ -46,12 +45,16 @@ constexpr int ROWBUF = 16;  // floats per row in the small per-row LDS arrays (>
 //   1:  64x128, 8 waves of 32x32   (rows >= 2048)
 //   2:  64x64,  4 waves of 32x32   (rows >= 1024)
 //   3:  32x64,  2 waves of 32x32   (smaller batches)
+constexpr int FBK = 32;
 template <int CFG> struct TileCfg;
-template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 4; };
-template <> struct TileCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M = 2, WAVES_N = 4; };
-template <> struct TileCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2; };
-template <> struct TileCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2; };
-template <> struct TileCfg<5> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 2; };  // probe: 4 waves of 64x64
+template <> struct TileCfg<0> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 4, BK = FBK; };
+template <> struct TileCfg<1> { static constexpr int BM = 64, BN = 128, WAVES_M = 2, WAVES_N = 4, BK = FBK; };
+template <> struct TileCfg<2> { static constexpr int BM = 64, BN = 64, WAVES_M = 2, WAVES_N = 2, BK = FBK; };
+template <> struct TileCfg<3> { static constexpr int BM = 32, BN = 64, WAVES_M = 1, WAVES_N = 2, BK = FBK; };
+template <> struct TileCfg<5> { static constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 2, BK = FBK; };  // probe: 4 waves of 64x64
+// probe (r03): 128x64, 4 waves of 64x32, K tiles of 16 - three LDS stages are 46 KB, so up to three workgroups share a CU and one's
+// prologue / epilogue / barriers can run under the others' K loops
+template <> struct TileCfg<7> { static constexpr int BM = 128, BN = 64, WAVES_M = 2, WAVES_N = 2, BK = 16; };
 constexpr int kNumTileCfg = 4;
 static const int kCfgBM[kNumTileCfg] = {128, 64, 64, 32};
 static const int kCfgBN[kNumTileCfg] = {128, 128, 64, 64};
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(TileCfg<CFG>::WAVES_M* TileCfg<CFG>::WAVES_N * 64) 
     FusedGemmArgs g, std::conditional_t<FUSE, FuseTail, NoTail> ft) {
   static_assert(!FUSE || EPI_RED, "the fused tail follows the partial-sum epilogue");
   using TC = TileCfg<CFG>;
-  constexpr int BM = TC::BM, BN = TC::BN, BK = FBK, FWAVES_M = TC::WAVES_M, FWAVES_N = TC::WAVES_N;
+  constexpr int BM = TC::BM, BN = TC::BN, BK = TC::BK, FWAVES_M = TC::WAVES_M, FWAVES_N = TC::WAVES_N;
   constexpr int NT = FWAVES_M * FWAVES_N * 64;
   // partial-sum epilogue: one slot = 64 columns for EVERY tile configuration, so the last Linear is summed in the same
   // order whatever the batch size (results are bit-identical across batch sizes)
@@ -2033,7 +2036,7 @@ template <bool EPI_RED, int CFG>
 static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
   using TC = TileCfg<CFG>;
   constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
-  constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (FBK + 4) * sizeof(float);
+  constexpr size_t smem = (size_t)3 * (TC::BM + TC::BN) * (TC::BK + 4) * sizeof(float);
   auto kern = k_flow_gemm<EPI_RED, CFG, false>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
@@ -2078,6 +2081,7 @@ hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArg
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
+  if (cfg == 7) return epi_red ? launch_fg<true, 7>(a, s) : launch_fg<false, 7>(a, s);
   if (cfg == kSkinny16Cfg || cfg == kSkinny16x16Cfg || cfg == kSkinny32v2Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
     const bool deep = (a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK;

@@ -680,7 +680,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->tune = variant == 159 ? (m->tune | IKF_TUNE_TILES16) : (m->tune & ~IKF_TUNE_TILES16);
     return IKF_OK;
   }
-  if (variant >= 100 && variant <= 107) {  // fused pipeline; 100 = tile by batch size, 101..107 = tile config 0..6
+  if (variant >= 100 && variant <= 108) {  // fused pipeline; 100 = tile by batch size, 101..108 = tile config 0..7
     m->gemm_variant = 100;
     m->tile_cfg = variant - 101;
     return IKF_OK;

@@ -243,8 +243,8 @@ const char* ikf_split_kernel_name(void);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
 const char* ikf_dominant_kernel_name(void);
 /* Select the flow pipeline (a tuning / test switch; every setting computes the same function):
- *   -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly, 101..107 the fused form with tile
- *   configuration 0..6 forced, 160 with the 16 x 32 small-batch tiles forced; 0..8 the unfused 4-kernel form with that tile variant;
+ *   -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly, 101..108 the fused form with tile
+ *   configuration 0..7 forced, 160 with the 16 x 32 small-batch tiles forced; 0..8 the unfused 4-kernel form with that tile variant;
  *   110 / 111 / 112  small-batch one-launch subnet head (entry kernel + first hidden contraction): off / automatic (default) / forced;
  *   120 / 121        next subnet's entry phase inside the preceding launch (row-tile arrival counter): off (default) / on;
  *   130 .. 134       write-through (sc1) activation stores: none / contractions / entry kernel / both / by batch size (default);
