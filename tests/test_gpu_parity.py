@@ -956,14 +956,14 @@ def _random_flow_configs(count, seed):
         out.append(dict(nb_nodes=int(rng.integers(1, 5)), dim=int(rng.integers(ndof, 17)), n_hidden=int(rng.integers(1, 5)),
                         width=int(rng.choice(widths)), robot_name=robot_name, softflow=bool(rng.integers(0, 2)),
                         sigmoid=bool(rng.integers(0, 4) == 0), seed=int(rng.integers(0, 1000)), gain=float(rng.choice([1.0, 1.5, 2.5])),
-                        n=int(rng.choice([1, 2, 31, 33, 200, 257, 513, 600, 1025, 1300])), clamp=bool(rng.integers(0, 2))))
+                        n=int(rng.choice([1, 2, 31, 33, 65, 100, 128, 129, 200, 256, 257, 513, 600, 1025, 1300])), clamp=bool(rng.integers(0, 2))))
     return out
 
 
 _FUZZ_STATS = {"runs": 0, "noise_branch": []}
 
 
-@pytest.mark.parametrize("cfg", _random_flow_configs(int(os.environ.get("IKF_FUZZ_COUNT", "32")), int(os.environ.get("IKF_FUZZ_SEED", "20260928"))), ids=lambda c: "-".join(str(v) for v in c.values()))
+@pytest.mark.parametrize("cfg", _random_flow_configs(int(os.environ.get("IKF_FUZZ_COUNT", "48")), int(os.environ.get("IKF_FUZZ_SEED", "20260928"))), ids=lambda c: "-".join(str(v) for v in c.values()))
 def test_flow_random_configurations(cfg):
     """Seeded random draws over everything IkflowModelParameters / glow_cNF_model (ikflow/model.py:17-41,300-354) can express within
     the boundary's limits - robot, nb_nodes, dim_latent_space up to 16, coeff_fn_config 1..4, any coeff_fn_internal_size, softflow on /
