@@ -920,7 +920,11 @@ __device__ __forceinline__ void skinny_tail(const FusedGemmArgs& g, const floatx
   IKF_TSTAMP(41)
 }
 
-template <bool EPI_RED, int NH, bool FUSE = false>
+// ILV: the first MFMA group's memory instructions (LDS store of the next A tile, its successor's global load) sit BETWEEN the group's
+// dependent MFMAs - in the shadow of the wave's own matrix-pipe latency - instead of in front of them.  Pays when several workgroups' or
+// 16 waves' worth of other work shares the SIMD (257 .. 768 rows: -1 .. -1.5 % per call), costs with one 8-wave workgroup per CU
+// (129 .. 256 rows: +1.6 %), so the launcher picks it by row count.
+template <bool EPI_RED, int NH, bool FUSE = false, bool ILV = false>
 __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArgs g, std::conditional_t<FUSE, FuseTail, NoTail> ft) {
   static_assert(!FUSE || EPI_RED, "the fused tail follows the partial-sum epilogue");
   constexpr int BM = KBM, BN = NH * 32, BK = KBK, NT = NH * KKS * 64, KS = KKS;
@@ -1015,10 +1019,24 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_flow_gemm_skinny(FusedGemmArg
   {                                                                                       \
     const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;                                       \
     IKK_FRAG(fa1, CUR, 1)                                                                 \
-    if (!(IKK_ABL & 2)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; } \
-    if (!(IKK_ABL & 4)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k2); }  \
-    IKK_PIN                                                                               \
-    IKK_MFMA(fa0, WC[0])                                                                  \
+    if constexpr (ILV) {                                                                  \
+      IKK_PIN                                                                             \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.x, WC[0].x, acc, 0, 0, 0);           \
+      IKK_PIN                                                                             \
+      if (!(IKK_ABL & 2)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; } \
+      IKK_PIN                                                                             \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.y, WC[0].y, acc, 0, 0, 0);           \
+      IKK_PIN                                                                             \
+      if (!(IKK_ABL & 4)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k2); }  \
+      IKK_PIN                                                                             \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.z, WC[0].z, acc, 0, 0, 0);           \
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0.w, WC[0].w, acc, 0, 0, 0);           \
+    } else {                                                                              \
+      if (!(IKK_ABL & 2)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) *reinterpret_cast<floatx4*>(smem + (NXT) * STAGE + ldst[i]) = rg[i]; } \
+      if (!(IKK_ABL & 4)) { _Pragma("unroll") for (int i = 0; i < NFA; ++i) rg[i] = IKK_LDA(i, k2); }  \
+      IKK_PIN                                                                             \
+      IKK_MFMA(fa0, WC[0])                                                                \
+    }                                                                                     \
     IKK_WLOAD(WC, 0)                                                                      \
     IKK_PIN                                                                               \
     if (!(IKK_ABL & 1)) __syncthreads();                                                  \
@@ -1861,15 +1879,22 @@ hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream
   return hipGetLastError();
 }
 
-template <bool EPI_RED, int NH>
-static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
+template <bool EPI_RED, int NH, bool ILV>
+static hipError_t launch_skinny_t(const FusedGemmArgs& a, hipStream_t s) {
   constexpr size_t smem = skinny_lds<NH>();
-  auto kern = k_flow_gemm_skinny<EPI_RED, NH, false>;
+  auto kern = k_flow_gemm_skinny<EPI_RED, NH, false, ILV>;
   static bool lds_ok[64] = {};
   if (hipError_t e = ensure_dynamic_lds(kern, smem, lds_ok); e != hipSuccess) return e;
   const long long grid = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a, NoTail{});
   return hipGetLastError();
+}
+template <bool EPI_RED, int NH>
+static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
+  // (the instruction order inside a stage does not change the arithmetic: same bits either way)
+  const long long tiles = (((long long)a.M + KBM - 1) / KBM) * (a.N / (NH * 32));
+  if (NH == 2 || tiles > 256) return launch_skinny_t<EPI_RED, NH, true>(a, s);
+  return launch_skinny_t<EPI_RED, NH, false>(a, s);
 }
 static hipError_t launch_skinny_tail(const FusedGemmArgs& a, const FuseTail& ft, hipStream_t s) {
   constexpr int NH = 2;
