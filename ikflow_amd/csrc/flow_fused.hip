@@ -1227,18 +1227,22 @@ __global__ __launch_bounds__(NH * KKS * 64) void k_entry_gemm_skinny(EntryArgs e
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.z, FB.z, acc, 0, 0, 0);                 \
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(FA.w, FB.w, acc, 0, 0, 0);                 \
   }
+  // the A fragments of k tile kt + 1 are read from LDS while tile kt's MFMAs run (clamped index: the last read is redundant)
 #define IKE_ITER(WC)                                                                      \
   {                                                                                       \
     const int k2 = (kt + 2 < KT) ? kt + 2 : KT - 1;                                       \
-    const floatx4 fa0 = *reinterpret_cast<const floatx4*>(fragA + kt * BK);               \
-    const floatx4 fa1 = *reinterpret_cast<const floatx4*>(fragA + kt * BK + 8);           \
+    const int k1 = (kt + 1 < KT) ? kt + 1 : KT - 1;                                       \
+    const floatx4 fn0 = *reinterpret_cast<const floatx4*>(fragA + k1 * BK);               \
+    const floatx4 fn1 = *reinterpret_cast<const floatx4*>(fragA + k1 * BK + 8);           \
     IKE_MFMA(fa0, WC[0])                                                                  \
     WC[0] = IKE_LDW(0, k2);                                                               \
     IKE_MFMA(fa1, WC[1])                                                                  \
     WC[1] = IKE_LDW(1, k2);                                                               \
+    fa0 = fn0; fa1 = fn1;                                                                 \
     ++kt;                                                                                 \
   }
   static_assert(KKG == 2, "two MFMA groups per wave per k tile");
+  floatx4 fa0 = *reinterpret_cast<const floatx4*>(fragA), fa1 = *reinterpret_cast<const floatx4*>(fragA + 8);
   for (int kt = 0; kt < KT;) {  // KT is even (launcher: K % (2*BK) == 0)
     IKE_ITER(w0)
     IKE_ITER(w1)
