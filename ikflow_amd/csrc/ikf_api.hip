@@ -113,7 +113,6 @@ struct ikf_model {
   float* ex_q = nullptr;          // [rows][ndof]
   uint8_t* ex_row_valid = nullptr;  // [rows]
   int* ex_pose_idx = nullptr;     // [poses]
-  uint8_t* ex_solved = nullptr;   // [poses]
   int* ex_block_scratch = nullptr;  // [2 * compact_blocks(poses)] per-block counts / offsets of the ordered compaction
   int* ex_count = nullptr;        // device
   int* h_count = nullptr;         // pinned host
@@ -207,9 +206,8 @@ static void free_exact(ikf_model* m) {
   if (m->ex_q) (void)hipFree(m->ex_q);
   if (m->ex_row_valid) (void)hipFree(m->ex_row_valid);
   if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
-  if (m->ex_solved) (void)hipFree(m->ex_solved);
   if (m->ex_block_scratch) (void)hipFree(m->ex_block_scratch);
-  m->ex_q = nullptr; m->ex_row_valid = nullptr; m->ex_pose_idx = nullptr; m->ex_solved = nullptr;
+  m->ex_q = nullptr; m->ex_row_valid = nullptr; m->ex_pose_idx = nullptr;
   m->ex_block_scratch = nullptr;
   m->exact_rows = m->exact_poses = 0;
 }
@@ -600,12 +598,10 @@ static ikf_status ensure_scratch(ikf_model* m, long long rows) {
 static ikf_status ensure_exact_poses(ikf_model* m, long long poses) {
   if (poses <= m->exact_poses) return IKF_OK;
   if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
-  if (m->ex_solved) (void)hipFree(m->ex_solved);
   if (m->ex_block_scratch) (void)hipFree(m->ex_block_scratch);
-  m->ex_pose_idx = nullptr; m->ex_solved = nullptr; m->ex_block_scratch = nullptr;
+  m->ex_pose_idx = nullptr; m->ex_block_scratch = nullptr;
   m->exact_poses = 0;
   IKF_HIP(hipMalloc(&m->ex_pose_idx, sizeof(int) * (size_t)poses));
-  IKF_HIP(hipMalloc(&m->ex_solved, (size_t)poses));
   IKF_HIP(hipMalloc(&m->ex_block_scratch, sizeof(int) * 2 * (size_t)(compact_blocks(poses) + 1)));
   m->exact_poses = poses;
   return IKF_OK;
@@ -1206,7 +1202,7 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
   if (n < 0) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n must be >= 0");
   if (!repeat_counts || n_rounds < 1 || n_rounds > IKF_MAX_ROUNDS)
     return fail(IKF_ERR_BAD_ARGUMENT, who + ": repeat_counts must hold 1..8 rounds");
-  if (n_lm_steps < 1) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n_lm_steps must be >= 1");
+  if (n_lm_steps < 1 || n_lm_steps > 255) return fail(IKF_ERR_BAD_ARGUMENT, who + ": n_lm_steps must be in 1..255");
   int max_repeat = 0;
   for (int r = 0; r < n_rounds; ++r) {
     if (repeat_counts[r] < 1) return fail(IKF_ERR_BAD_ARGUMENT, who + ": repeat counts must be >= 1");
@@ -1259,13 +1255,10 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
       st = run_flow_guarded(m, ps, d_latent, rows, /*clamp=*/1, m->ex_q, s);  // seeds (:188)
       if (st != IKF_OK) return st;
     }
-    IKF_HIP(hipMemsetAsync(m->ex_solved, 0, (size_t)n_active, s));
-    for (int it = 0; it < n_lm_steps; ++it) {
-      IKF_HIP(launch_exact_lm_iter(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, m->ex_q,
-                                   m->ex_solved, m->ex_row_valid, pos_thr, rot_thr, s));
-      IKF_HIP(launch_exact_select(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, m->ex_solved,
-                                  d_q_out, d_valid_out, s));
-    }
+    // all LM iterations of the round in one launch + one selection (kin_kernels.hip: k_exact_lm_iters)
+    IKF_HIP(launch_exact_lm_iters(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, n_lm_steps, m->ex_q,
+                                  m->ex_row_valid, pos_thr, rot_thr, s));
+    IKF_HIP(launch_exact_select_first(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, d_q_out, d_valid_out, s));
     if (h_stats) {
       h_stats[4 * r + 0] = n_active;
       h_stats[4 * r + 1] = rows;

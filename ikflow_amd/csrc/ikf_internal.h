@@ -286,12 +286,12 @@ hipError_t launch_pose_distance(const float* a, const float* b, long long n, flo
                                 hipStream_t s);
 hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int ncols, const float* q, long long n,
                                         uint8_t* out, hipStream_t s);
-hipError_t launch_exact_lm_iter(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx,
-                                int n_active, int repeat, float* q, const uint8_t* solved, uint8_t* row_valid,
-                                float pos_thr, float rot_thr, hipStream_t s);
-hipError_t launch_exact_select(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
-                               const uint8_t* row_valid, uint8_t* solved, float* q_out, uint8_t* valid_out,
-                               hipStream_t s);
+// exact IK: all LM iterations of a round in one launch (row_valid_iter[row] = iteration, 1-based, at which the row first met the
+// thresholds, 0 = never; q keeps that iteration's value) and the per-pose selection (earliest iteration, highest repeat within it)
+hipError_t launch_exact_lm_iters(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
+                                 int n_steps, float* q, uint8_t* row_valid_iter, float pos_thr, float rot_thr, hipStream_t s);
+hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
+                                     const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, hipStream_t s);
 // ordered list of the indices with valid[i] == 0 and their count; block_scratch: 2 * compact_blocks(n) ints
 long long compact_blocks(long long n);
 hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, int* block_scratch,

@@ -446,47 +446,60 @@ __global__ __launch_bounds__(64) void k_self_collision(const Chain* __restrict__
 // active pose j (cond.repeat((R,1)), ikflow_solver.py:185).  Poses solved in an earlier iteration are masked instead
 // of physically compacted (rows are independent, so the results are identical to the reference's q[mask] compaction).
 // ---------------------------------------------------------------------------------------------------------------
+// All LM iterations of a retry round in ONE launch (r03; one launch + one selection per iteration before: the exact path is a latency
+// chain at small sizes and six launches of ~6 us were a third of a converged call's overhead).  The reference's loop
+// (ikflow_solver.py:199-233) runs, per iteration: one LM step on every row of the still-unsolved poses, validity of every row, per pose the
+// pick among its valid repeats, and drops the rows of solved poses.  Row-wise that is: a row keeps stepping until IT is valid (its pose is
+// then solved in that iteration at the latest), and a pose is solved in the FIRST iteration in which any of its repeats is valid, by the
+// highest such repeat.  So each row records the iteration at which it first became valid (1-based; 0 = never) and keeps that q; the
+// selection takes the earliest iteration over a pose's repeats and the highest repeat among those.  (A repeat whose pose was solved by a
+// sibling keeps stepping to the end - work the loop form skips, results it never reads.)
 template <int NDOF>
-__global__ __launch_bounds__(256) void k_exact_lm_iter(const Chain* __restrict__ ch, const float* __restrict__ poses,
-                                                       const int* __restrict__ pose_idx, int n_active, int repeat,
-                                                       float* __restrict__ q, const uint8_t* __restrict__ solved,
-                                                       uint8_t* __restrict__ row_valid, float pos_thr, float rot_thr) {
+__global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict__ ch, const float* __restrict__ poses,
+                                                        const int* __restrict__ pose_idx, int n_active, int repeat, int n_steps,
+                                                        float* __restrict__ q, uint8_t* __restrict__ row_valid_iter,
+                                                        float pos_thr, float rot_thr) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= (long long)n_active * repeat) return;
   const int j = (int)(row % n_active);
-  if (solved[j]) {
-    row_valid[row] = 0;
-    return;
-  }
   const float* tgt = poses + (size_t)pose_idx[j] * 7;
   float qv[NDOF];
   load_q<NDOF>(q, row, qv);
-  lm_step_row<NDOF>(ch, tgt, qv);
-#pragma unroll
-  for (int k = 0; k < NDOF; ++k) q[(size_t)row * NDOF + k] = qv[k];
-  float pe, re;
-  pose_error_f32<NDOF>(ch, qv, tgt, &pe, &re);
-  row_valid[row] = (pe < pos_thr && re < rot_thr) ? 1 : 0;  // ikflow_solver.py:211
-}
-
-__global__ __launch_bounds__(256) void k_exact_select(int ndof, const int* __restrict__ pose_idx, int n_active,
-                                                      int repeat, const float* __restrict__ q,
-                                                      const uint8_t* __restrict__ row_valid,
-                                                      uint8_t* __restrict__ solved, float* __restrict__ q_out,
-                                                      uint8_t* __restrict__ valid_out) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_active || solved[j]) return;
-  // ascending scan of valid_idxs with sol_idx = idx % n_invalid: the highest valid repeat wins (ikflow_solver.py:217-222)
-  for (int r = repeat - 1; r >= 0; --r) {
-    const long long row = (long long)r * n_active + j;
-    if (row_valid[row]) {
-      const int dst = pose_idx[j];
-      for (int k = 0; k < ndof; ++k) q_out[(size_t)dst * ndof + k] = q[(size_t)row * ndof + k];
-      valid_out[dst] = 1;
-      solved[j] = 1;
+  int first = 0;
+  for (int it = 0; it < n_steps; ++it) {
+    lm_step_row<NDOF>(ch, tgt, qv);
+    float pe, re;
+    pose_error_f32<NDOF>(ch, qv, tgt, &pe, &re);
+    if (pe < pos_thr && re < rot_thr) {  // ikflow_solver.py:211
+      first = it + 1;
       break;
     }
   }
+#pragma unroll
+  for (int k = 0; k < NDOF; ++k) q[(size_t)row * NDOF + k] = qv[k];
+  row_valid_iter[row] = (uint8_t)first;
+}
+
+__global__ __launch_bounds__(256) void k_exact_select_first(int ndof, const int* __restrict__ pose_idx, int n_active,
+                                                            int repeat, const float* __restrict__ q,
+                                                            const uint8_t* __restrict__ row_valid_iter,
+                                                            float* __restrict__ q_out, uint8_t* __restrict__ valid_out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_active) return;
+  // ascending scan of valid_idxs with sol_idx = idx % n_invalid: the highest valid repeat of the iteration wins (ikflow_solver.py:217-222)
+  int best_it = 256, best_r = -1;
+  for (int r = repeat - 1; r >= 0; --r) {
+    const int it = row_valid_iter[(long long)r * n_active + j];
+    if (it != 0 && it < best_it) {
+      best_it = it;
+      best_r = r;
+    }
+  }
+  if (best_r < 0) return;
+  const long long row = (long long)best_r * n_active + j;
+  const int dst = pose_idx[j];
+  for (int k = 0; k < ndof; ++k) q_out[(size_t)dst * ndof + k] = q[(size_t)row * ndof + k];
+  valid_out[dst] = 1;
 }
 
 // ordered compaction of the indices with valid[i] == 0 (boolean-mask indexing, ikflow_solver.py:389).
@@ -663,22 +676,20 @@ hipError_t launch_self_collision(const Chain* ch, const CollisionModel* cm, int 
                                              min_dist, colliding));
   return hipGetLastError();
 }
-hipError_t launch_exact_lm_iter(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active,
-                                int repeat, float* q, const uint8_t* solved, uint8_t* row_valid, float pos_thr,
-                                float rot_thr, hipStream_t s) {
+hipError_t launch_exact_lm_iters(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
+                                 int n_steps, float* q, uint8_t* row_valid_iter, float pos_thr, float rot_thr, hipStream_t s) {
   const long long rows = (long long)n_active * repeat;
   if (rows <= 0) return hipSuccess;
-  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iter<ND>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch,
-                                             poses, pose_idx, n_active, repeat, q, solved, row_valid, pos_thr,
-                                             rot_thr));
+  if (n_steps > 255) return hipErrorInvalidValue;  // (the first-valid iteration is recorded in a byte)
+  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iters<ND>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch,
+                                             poses, pose_idx, n_active, repeat, n_steps, q, row_valid_iter, pos_thr, rot_thr));
   return hipGetLastError();
 }
-hipError_t launch_exact_select(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
-                               const uint8_t* row_valid, uint8_t* solved, float* q_out, uint8_t* valid_out,
-                               hipStream_t s) {
+hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
+                                     const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, hipStream_t s) {
   if (n_active <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_exact_select, dim3(blocks_for(n_active, 256)), dim3(256), 0, s, ndof, pose_idx, n_active,
-                     repeat, q, row_valid, solved, q_out, valid_out);
+  hipLaunchKernelGGL(k_exact_select_first, dim3(blocks_for(n_active, 256)), dim3(256), 0, s, ndof, pose_idx, n_active,
+                     repeat, q, row_valid_iter, q_out, valid_out);
   return hipGetLastError();
 }
 long long compact_blocks(long long n) { return (n + kCompactBlock - 1) / kCompactBlock; }

@@ -181,7 +181,7 @@ typedef const float* (*ikf_latent_fn)(void* user, int round, int64_t rows, int d
 
 /* d_target_poses [n x 7]; repeat_counts[n_rounds]; thresholds as in :349-350.
  * Outputs: d_q_out [n x ndof] (rows never solved stay 0.0, :197), d_valid_out [n] (0/1).
- * n_lm_steps: the reference's n_opt_steps_max = 3 (:364).
+ * n_lm_steps: the reference's n_opt_steps_max = 3 (:364); 1 .. 255 (all iterations of a round run in one launch).
  * h_stats (nullable, 4*n_rounds int64): per round {poses entering, flow rows, LM row-iterations, poses solved}. */
 ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t n, const int32_t* repeat_counts,
                               int n_rounds, int n_lm_steps, float pos_error_threshold, float rot_error_threshold,
