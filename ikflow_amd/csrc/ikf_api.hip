@@ -1223,14 +1223,13 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
   StreamScope scope(m, s);
   IKF_HIP(scope.enter());
 
-  IKF_HIP(hipMemsetAsync(d_q_out, 0, sizeof(float) * (size_t)n * ndof, s));  // unsolved rows stay 0.0 (:197)
-  IKF_HIP(hipMemsetAsync(d_valid_out, 0, (size_t)n, s));
-
+  // (no memset of the outputs: round 0's selection writes every pose - its solution, or zeros and valid = 0 (:197))
   long long n_active = n;
   for (int r = 0; r < n_rounds; ++r) {
     const int R = repeat_counts[r];
-    // active pose list = ordered indices of still-invalid poses (identity in round 0)
-    IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, m->ex_block_scratch, s));
+    // active pose list = ordered indices of still-invalid poses (every pose in round 0)
+    if (r == 0) IKF_HIP(launch_all_active(n, m->ex_pose_idx, m->ex_count, s));
+    else IKF_HIP(launch_compact_invalid(d_valid_out, n, m->ex_pose_idx, m->ex_count, m->ex_block_scratch, s));
     if (r > 0) {
       IKF_HIP(hipMemcpyAsync(m->h_count, m->ex_count, sizeof(int), hipMemcpyDeviceToHost, s));
       IKF_HIP(hipStreamSynchronize(s));
@@ -1258,7 +1257,8 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
     // all LM iterations of the round in one launch + one selection (kin_kernels.hip: k_exact_lm_iters)
     IKF_HIP(launch_exact_lm_iters(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, n_lm_steps, m->ex_q,
                                   m->ex_row_valid, pos_thr, rot_thr, s));
-    IKF_HIP(launch_exact_select_first(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, d_q_out, d_valid_out, s));
+    IKF_HIP(launch_exact_select_first(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, d_q_out, d_valid_out,
+                                      r == 0 ? 1 : 0, s));
     if (h_stats) {
       h_stats[4 * r + 0] = n_active;
       h_stats[4 * r + 1] = rows;

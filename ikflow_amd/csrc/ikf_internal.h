@@ -291,7 +291,8 @@ hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int nc
 hipError_t launch_exact_lm_iters(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
                                  int n_steps, float* q, uint8_t* row_valid_iter, float pos_thr, float rot_thr, hipStream_t s);
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
-                                     const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, hipStream_t s);
+                                     const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, int init, hipStream_t s);
+hipError_t launch_all_active(long long n, int* idx_out, int* count_out, hipStream_t s);  // idx = 0 .. n-1, count = n (round 0)
 // ordered list of the indices with valid[i] == 0 and their count; block_scratch: 2 * compact_blocks(n) ints
 long long compact_blocks(long long n);
 hipError_t launch_compact_invalid(const uint8_t* valid, long long n, int* idx_out, int* count_out, int* block_scratch,

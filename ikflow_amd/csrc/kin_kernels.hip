@@ -480,10 +480,12 @@ __global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict_
   row_valid_iter[row] = (uint8_t)first;
 }
 
+// init (round 0, where every pose is active): a pose without a valid repeat gets its row of zeros and valid = 0 here (ikflow_solver.py:197),
+// so the caller's output buffers need no memset before the call.
 __global__ __launch_bounds__(256) void k_exact_select_first(int ndof, const int* __restrict__ pose_idx, int n_active,
                                                             int repeat, const float* __restrict__ q,
                                                             const uint8_t* __restrict__ row_valid_iter,
-                                                            float* __restrict__ q_out, uint8_t* __restrict__ valid_out) {
+                                                            float* __restrict__ q_out, uint8_t* __restrict__ valid_out, int init) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n_active) return;
   // ascending scan of valid_idxs with sol_idx = idx % n_invalid: the highest valid repeat of the iteration wins (ikflow_solver.py:217-222)
@@ -495,11 +497,24 @@ __global__ __launch_bounds__(256) void k_exact_select_first(int ndof, const int*
       best_r = r;
     }
   }
-  if (best_r < 0) return;
-  const long long row = (long long)best_r * n_active + j;
   const int dst = pose_idx[j];
+  if (best_r < 0) {
+    if (init) {
+      for (int k = 0; k < ndof; ++k) q_out[(size_t)dst * ndof + k] = 0.f;
+      valid_out[dst] = 0;
+    }
+    return;
+  }
+  const long long row = (long long)best_r * n_active + j;
   for (int k = 0; k < ndof; ++k) q_out[(size_t)dst * ndof + k] = q[(size_t)row * ndof + k];
   valid_out[dst] = 1;
+}
+
+// round 0's active list: every pose, in order
+__global__ __launch_bounds__(256) void k_iota(int* __restrict__ idx, long long n, int* __restrict__ count_out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = (int)i;
+  if (i == 0) *count_out = (int)n;
 }
 
 // ordered compaction of the indices with valid[i] == 0 (boolean-mask indexing, ikflow_solver.py:389).
@@ -686,10 +701,15 @@ hipError_t launch_exact_lm_iters(const Chain* ch, int ndof, const float* poses, 
   return hipGetLastError();
 }
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
-                                     const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, hipStream_t s) {
+                                     const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, int init, hipStream_t s) {
   if (n_active <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_exact_select_first, dim3(blocks_for(n_active, 256)), dim3(256), 0, s, ndof, pose_idx, n_active,
-                     repeat, q, row_valid_iter, q_out, valid_out);
+                     repeat, q, row_valid_iter, q_out, valid_out, init);
+  return hipGetLastError();
+}
+hipError_t launch_all_active(long long n, int* idx_out, int* count_out, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_iota, dim3(blocks_for(n, 256)), dim3(256), 0, s, idx_out, n, count_out);
   return hipGetLastError();
 }
 long long compact_blocks(long long n) { return (n + kCompactBlock - 1) / kCompactBlock; }

@@ -180,7 +180,8 @@ ikf_status ikf_limits_exceeded(const float* d_q, int64_t n, int n_cols, const fl
 typedef const float* (*ikf_latent_fn)(void* user, int round, int64_t rows, int dim);
 
 /* d_target_poses [n x 7]; repeat_counts[n_rounds]; thresholds as in :349-350.
- * Outputs: d_q_out [n x ndof] (rows never solved stay 0.0, :197), d_valid_out [n] (0/1).
+ * Outputs: d_q_out [n x ndof] (rows never solved are 0.0, :197), d_valid_out [n] (0/1); every entry is written on success (the
+ * buffers need no clearing by the caller), their contents are unspecified when the call returns an error.
  * n_lm_steps: the reference's n_opt_steps_max = 3 (:364); 1 .. 255 (all iterations of a round run in one launch).
  * h_stats (nullable, 4*n_rounds int64): per round {poses entering, flow rows, LM row-iterations, poses solved}. */
 ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t n, const int32_t* repeat_counts,
