@@ -1243,10 +1243,10 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
       st = ensure_exact_rows(m, rows);
       if (st != IKF_OK) return st;
     }
+    const float* d_q_seed = m->ex_q;
     if (seed_fn) {
-      const float* d_seeds = seed_fn(user, r, n_active, R, m->ex_pose_idx, ndof);
-      if (!d_seeds) return fail(IKF_ERR_NULL_POINTER, who + ": seed_fn returned null");
-      IKF_HIP(hipMemcpyAsync(m->ex_q, d_seeds, sizeof(float) * (size_t)rows * ndof, hipMemcpyDeviceToDevice, s));
+      d_q_seed = seed_fn(user, r, n_active, R, m->ex_pose_idx, ndof);  // read in place by the LM kernel (no copy)
+      if (!d_q_seed) return fail(IKF_ERR_NULL_POINTER, who + ": seed_fn returned null");
     } else {
       const float* d_latent = latent_fn(user, r, rows, m->dims.D);
       if (!d_latent) return fail(IKF_ERR_NULL_POINTER, who + ": latent_fn returned null");
@@ -1255,7 +1255,7 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
       if (st != IKF_OK) return st;
     }
     // all LM iterations of the round in one launch + one selection (kin_kernels.hip: k_exact_lm_iters)
-    IKF_HIP(launch_exact_lm_iters(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, n_lm_steps, m->ex_q,
+    IKF_HIP(launch_exact_lm_iters(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, n_lm_steps, d_q_seed, m->ex_q,
                                   m->ex_row_valid, pos_thr, rot_thr, s));
     IKF_HIP(launch_exact_select_first(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, d_q_out, d_valid_out,
                                       r == 0 ? 1 : 0, s));

@@ -457,14 +457,14 @@ __global__ __launch_bounds__(64) void k_self_collision(const Chain* __restrict__
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict__ ch, const float* __restrict__ poses,
                                                         const int* __restrict__ pose_idx, int n_active, int repeat, int n_steps,
-                                                        float* __restrict__ q, uint8_t* __restrict__ row_valid_iter,
-                                                        float pos_thr, float rot_thr) {
+                                                        const float* q_in, float* q, uint8_t* __restrict__ row_valid_iter,
+                                                        float pos_thr, float rot_thr) {  // q_in: the seeds (may be q itself)
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= (long long)n_active * repeat) return;
   const int j = (int)(row % n_active);
   const float* tgt = poses + (size_t)pose_idx[j] * 7;
   float qv[NDOF];
-  load_q<NDOF>(q, row, qv);
+  load_q<NDOF>(q_in, row, qv);
   int first = 0;
   for (int it = 0; it < n_steps; ++it) {
     lm_step_row<NDOF>(ch, tgt, qv);
@@ -692,12 +692,13 @@ hipError_t launch_self_collision(const Chain* ch, const CollisionModel* cm, int 
   return hipGetLastError();
 }
 hipError_t launch_exact_lm_iters(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
-                                 int n_steps, float* q, uint8_t* row_valid_iter, float pos_thr, float rot_thr, hipStream_t s) {
+                                 int n_steps, const float* q_in, float* q, uint8_t* row_valid_iter, float pos_thr, float rot_thr,
+                                 hipStream_t s) {
   const long long rows = (long long)n_active * repeat;
   if (rows <= 0) return hipSuccess;
   if (n_steps > 255) return hipErrorInvalidValue;  // (the first-valid iteration is recorded in a byte)
   IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iters<ND>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch,
-                                             poses, pose_idx, n_active, repeat, n_steps, q, row_valid_iter, pos_thr, rot_thr));
+                                             poses, pose_idx, n_active, repeat, n_steps, q_in, q, row_valid_iter, pos_thr, rot_thr));
   return hipGetLastError();
 }
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,

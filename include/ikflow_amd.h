@@ -194,6 +194,7 @@ ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t
  * still unsolved; the callback returns a DEVICE pointer to [n_active * repeat x ndof] fp32 clamped seeds laid out
  * tile-major (row = r * n_active + j  <->  repeat r of pose d_active_idx[j]; `conditional.repeat((R,1))`, :185).  The
  * stream is idle when the callback runs in rounds > 0 (the count was just read); in round 0 every pose is active.
+ * The seeds are read in place by kernels enqueued on `stream` (not copied, not modified): the buffer must stay valid until then.
  * Everything after `self._run_inference` (:188) is exercised: LM iterations (:199-209), validity (:210-211), "highest
  * valid repeat wins" (:217-222), slot order (:224-225), compaction (:231-233) and the retry rounds (:383-408).
  * Needs no weights. */
