@@ -1,0 +1,323 @@
+// Row-owner flow kernel (gfx950): ONE launch per call; workgroup w keeps rows [16 w, 16 w + 16) on chip for the whole inverse pass
+// (ikflow/ikflow_solver.py:98 -> GraphINN rev over ikflow/model.py:336-352: every GLOWCouplingBlock's two subnets, PermuteRandom^-1,
+// then FixedLinearTransform^-1, [:, :ndof], clamp - ikflow_solver.py:99-102).
+//
+//   * state [16][D], the conditional and the 16 x 1024 hidden activation tile live in LDS (two tiles, ping-pong: one barrier per layer);
+//   * the hidden contractions run transposed on v_mfma_f32_16x16x4_f32 (A operand = 16 output columns of W, B operand = the 16 rows):
+//     wave v owns columns [128 v, 128 v + 128) = 8 accumulator blocks of 4 registers, whose lane layout (row = lane % 16, four
+//     consecutive columns 4 (lane / 16) + r) goes back to the tile as one ds_write_b128 per block;
+//   * every parameter of a subnet reaches the wave through ONE linear stream of 8 KB groups (rowowner_pack below) consumed in order
+//     through a ring of register slots, requested PF groups ahead of use and never drained - not at barriers, not between subnets:
+//       group 0          first Linear  [16 k: x inputs, 7 pose entries, softflow column, zeros, bias at k = 15] x the wave's 128 columns
+//       group 1 / 66     bias of hidden Linear 2 / 3 in accumulator layout (the accumulators START from it)
+//       group 2..65      hidden Linear 2, 16 k per group            group 67..130  hidden Linear 3
+//       group 131        last Linear, the wave's 128-k slice x 16 outputs (zero rows beyond n_out)
+//     132 groups per subnet = a multiple of the ring length, so every group sits in a slot known at compile time;
+//   * rows are independent: no inter-workgroup synchronisation, no activation ever goes to HBM, no entry / finalize launches.
+// The price is the weight stream: every CU reads every weight (32 B/clk/CU from its XCD's L2 while the matrix pipe runs flat out).
+// Numerics: exact f32 fma chains on the matrix pipe like the per-layer kernels; another summation order (k ascending inside 16-k
+// groups permuted as k = 16 g + 4 j + c -> (c, j)), same tolerance against the oracle.
+#include "ikf_internal.h"
+
+namespace ikf {
+
+typedef float ro_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned ro_u4 __attribute__((ext_vector_type(4)));
+
+constexpr int RO_W = 1024;                       // hidden width this kernel is built for
+constexpr int RO_ROWS = 16;
+constexpr int RO_LDA = RO_W + 4;                 // tile row stride in floats
+constexpr int RO_WAVES = 8;
+constexpr int RO_NCB = 8;                        // 16-column accumulator blocks per wave
+constexpr int RO_KG = RO_W / 16;                 // 16-k groups per hidden layer (64)
+constexpr int RO_SUB_GROUPS = 2 + 2 * (1 + RO_KG);   // 132
+constexpr unsigned RO_WAVE_GROUP_BYTES = RO_NCB * 64 * 16;          // 8 KB: one ring slot of one wave
+constexpr unsigned RO_GROUP_BYTES = RO_WAVES * RO_WAVE_GROUP_BYTES;  // 64 KB
+constexpr int RO_MAX_SUB = 32;
+constexpr int RO_US = 20, RO_RS = 20;            // row strides of the small LDS arrays
+constexpr int RO_SMALL_WORDS = 36;
+// LDS map (floats)
+constexpr int RO_OFF_TILE0 = 0;
+constexpr int RO_OFF_TILE1 = RO_ROWS * RO_LDA;
+constexpr int RO_OFF_XS = 2 * RO_ROWS * RO_LDA;            // [2][16][16] state, ping-pong
+constexpr int RO_OFF_US = RO_OFF_XS + 2 * 256;             // [16][20] first-Linear input rows
+constexpr int RO_OFF_RED = RO_OFF_US + RO_ROWS * RO_US;    // [8][16][20] last-Linear partial sums per wave
+constexpr int RO_OFF_COND = RO_OFF_RED + RO_WAVES * RO_ROWS * RO_RS;  // [16][8] pose + softflow
+constexpr int RO_OFF_SMALL = RO_OFF_COND + RO_ROWS * 8;    // [n_sub][36] b_last, perm_inv, which / n_x / x_off / n_half
+constexpr int RO_LDS_FLOATS = RO_OFF_SMALL + RO_MAX_SUB * RO_SMALL_WORDS;
+constexpr size_t RO_LDS_BYTES = sizeof(float) * RO_LDS_FLOATS;
+
+static_assert(sizeof(RoSubnet) == RO_SMALL_WORDS * 4, "RoSubnet layout");
+
+__device__ __forceinline__ void ro_barrier() {
+  // LDS traffic of this wave done, then the workgroup barrier; the weight-stream loads stay in flight
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// value of new-state element d of row `row` after the pending coupling of subnet `sm` (or the plain state when sm == null)
+__device__ __forceinline__ float ro_new_state(const float* __restrict__ xs_old, const float* __restrict__ red, const float* __restrict__ sm,
+                                              int row, int d, int L1, float clamp) {
+  if (sm == nullptr) return xs_old[row * 16 + d];
+  const int* smi = reinterpret_cast<const int*>(sm);
+  const int which = smi[32], nl = smi[35];
+  const int src = which == 2 ? smi[16 + d] : d;
+  const int off = which == 1 ? L1 : 0;
+  float v = xs_old[row * 16 + src];
+  if (src >= off && src < off + nl) {
+    const int j = src - off;
+    float s = sm[j], tt = sm[nl + j];
+#pragma unroll
+    for (int w = 0; w < RO_WAVES; ++w) {
+      s += red[w * (RO_ROWS * RO_RS) + row * RO_RS + j];
+      tt += red[w * (RO_ROWS * RO_RS) + row * RO_RS + nl + j];
+    }
+    const float s_cl = clamp * (0.636f * atanf(s));
+    v = (v - tt) * expf(-s_cl);
+  }
+  return v;
+}
+
+#define RO_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NBUF>
+__global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
+  static_assert(RO_SUB_GROUPS % NBUF == 0 && RO_KG % NBUF == 0, "ring length must divide the subnet's group count");
+  constexpr int PF = NBUF - 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const tile0 = smem + RO_OFF_TILE0;
+  float* const tile1 = smem + RO_OFF_TILE1;
+  float* const xs = smem + RO_OFF_XS;
+  float* const us = smem + RO_OFF_US;
+  float* const red = smem + RO_OFF_RED;
+  float* const cond = smem + RO_OFF_COND;
+  float* const small = smem + RO_OFF_SMALL;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int m0 = blockIdx.x * RO_ROWS;
+  const int lrow = lane & 15, lq = lane >> 4;
+#define RO_STAMP(i) if (a.trace != nullptr && t == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+  RO_STAMP(0)
+
+  // ---- the weight stream: ring of NBUF slots x 8 float4 per lane
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.stream), 0, a.stream_bytes, 0x00020000);
+  const unsigned voff = lane * 16;
+  unsigned g_issue = wave * RO_WAVE_GROUP_BYTES;   // byte offset of the next group to request (wave-uniform)
+  ro_f4 wb[NBUF][RO_NCB];
+#define RO_ISSUE(slot)                                                                                                             \
+  {                                                                                                                                \
+    const unsigned so_ = __builtin_amdgcn_readfirstlane(g_issue);                                                                  \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_)                                                                       \
+        wb[slot][cb_] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cb_ * 1024, so_, 0));           \
+    g_issue += RO_GROUP_BYTES;                                                                                                     \
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s) RO_ISSUE(s)
+
+  // ---- rows: state, conditional, per-subnet small parameters -> LDS
+  if (t < 256) {
+    const int row = t >> 4, d = t & 15;
+    int gr = m0 + row;
+    gr = gr < a.M ? gr : a.M - 1;
+    xs[row * 16 + d] = d < a.D ? a.x0[(size_t)gr * a.D + d] : 0.f;
+  } else if (t < 256 + 128) {
+    const int row = (t - 256) >> 3, k = t & 7;
+    int gr = m0 + row;
+    gr = gr < a.M ? gr : a.M - 1;
+    const long long grow = a.row0 + gr;
+    const long long pm = grow < a.ps.n_mod ? grow : (a.ps.n_mod == 1 ? 0 : grow % a.ps.n_mod);
+    const long long pi = a.ps.idx ? (long long)a.ps.idx[pm] : pm;
+    cond[row * 8 + k] = k < 7 ? a.ps.poses[pi * a.ps.stride + k] : a.ps.softflow;
+  }
+  for (int i = t; i < a.n_sub * RO_SMALL_WORDS; i += RO_WAVES * 64) small[i] = reinterpret_cast<const float*>(a.sub)[i];
+  ro_barrier();
+
+  // input rows of subnet `nxt` from the state after the pending coupling of subnet `pend` (null: none) - threads 256..511;
+  // the new state itself - threads 0..255
+  auto advance = [&](const float* pend_sm, const float* nxt_sm, const float* xs_old, float* xs_new) {
+    if (t < 256) {
+      const int row = t >> 4, d = t & 15;
+      if (d < a.D) xs_new[row * 16 + d] = ro_new_state(xs_old, red, pend_sm, row, d, a.L1, a.clamp);
+    } else if (nxt_sm != nullptr) {
+      const int row = (t - 256) >> 4, k = t & 15;
+      const int* ni = reinterpret_cast<const int*>(nxt_sm);
+      const int n_x = ni[33], x_off = ni[34];
+      float v = 0.f;
+      if (k < n_x) v = ro_new_state(xs_old, red, pend_sm, row, x_off + k, a.L1, a.clamp);
+      else if (k < n_x + 8) v = cond[row * 8 + (k - n_x)];
+      else if (k == 15) v = 1.0f;
+      us[row * RO_US + k] = v;
+    }
+  };
+  advance(nullptr, small, xs, xs + 256);
+  ro_barrier();
+  int xcur = 1;   // xs + 256 * xcur holds the current state
+
+  ro_f4 acc[RO_NCB];
+  ro_f4 af[2];
+#define RO_EPILOGUE(tile_out)                                                                                            \
+  _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) {                                                             \
+    ro_f4 v_ = acc[cb_];                                                                                                 \
+    v_ = __builtin_elementwise_max(v_, v_ * a.slope); /* LeakyReLU for 0 <= slope <= 1 (the launcher checks) */         \
+    *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + wave * 128 + cb_ * 16 + 4 * lq) = v_;                         \
+  }
+#define RO_AFRAG(tile_in, kg) *reinterpret_cast<const ro_f4*>((tile_in) + lrow * RO_LDA + (kg) * 16 + 4 * lq)
+  // one 16-k group: request the group PF ahead into the slot consumed last, read the next A fragment, 32 MFMAs
+#define RO_KGSTEP(slot, tile_in, kg, par)                                                                                \
+  {                                                                                                                      \
+    RO_ISSUE(((slot) + PF) % NBUF)                                                                                       \
+    af[(par) ^ 1] = RO_AFRAG(tile_in, (kg) + 1);                                                                         \
+    _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                                     \
+        _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) acc[cb_] = RO_MFMA(wb[slot][cb_][c_], af[par][c_], acc[cb_]);  \
+    /* pinned order: the A fragment read, then one weight request per four MFMAs */                                      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < RO_NCB; ++i_) {                                                              \
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                                 \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                 \
+    }                                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  }
+  // a hidden layer: accumulators start from the bias group (slot SB), then 64 groups starting in slot (SB + 1) % NBUF
+#define RO_LAYER(SB, tile_in, tile_out)                                                                                  \
+  {                                                                                                                      \
+    RO_ISSUE(((SB) + PF) % NBUF)                                                                                         \
+    af[0] = RO_AFRAG(tile_in, 0);                                                                                        \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) acc[cb_] = wb[SB][cb_];                                     \
+    for (int kg = 0; kg < RO_KG; kg += NBUF) {                                                                           \
+      _Pragma("unroll") for (int u_ = 0; u_ < NBUF; ++u_) RO_KGSTEP(((SB) + 1 + u_) % NBUF, tile_in, kg + u_, u_ & 1)    \
+    }                                                                                                                    \
+    RO_EPILOGUE(tile_out)                                                                                                \
+    ro_barrier();                                                                                                        \
+  }
+  static_assert(NBUF % 2 == 0 || NBUF == 0, "the A-fragment parity is tied to the ring position: NBUF must be even");
+
+  for (int s = 0; s < a.n_sub; ++s) {
+    const float* sm = small + s * RO_SMALL_WORDS;
+    RO_STAMP(1 + (s < 31 ? s : 31))
+    // ---- group 0 (slot 0): first Linear + LeakyReLU -> tile0
+    {
+      RO_ISSUE(PF % NBUF)
+      const ro_f4 uf = *reinterpret_cast<const ro_f4*>(us + lrow * RO_US + 4 * lq);
+#pragma unroll
+      for (int cb = 0; cb < RO_NCB; ++cb) acc[cb] = ro_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int cb = 0; cb < RO_NCB; ++cb) acc[cb] = RO_MFMA(wb[0][cb][c], uf[c], acc[cb]);
+      RO_EPILOGUE(tile0)
+      ro_barrier();
+    }
+    // ---- groups 1..65: hidden Linear 2 (tile0 -> tile1); groups 66..130: hidden Linear 3 (tile1 -> tile0)
+    RO_LAYER(1 % NBUF, tile0, tile1)
+    RO_LAYER(66 % NBUF, tile1, tile0)
+    // ---- group 131: last Linear, this wave's 128-k slice; partial sums [row][16 outputs] -> red[wave]
+    {
+      RO_ISSUE((131 + PF) % NBUF)
+      constexpr int SL = 131 % NBUF;
+      ro_f4 hf[RO_NCB];
+#pragma unroll
+      for (int j = 0; j < RO_NCB; ++j) hf[j] = *reinterpret_cast<const ro_f4*>(tile0 + lrow * RO_LDA + wave * 128 + j * 16 + 4 * lq);
+      ro_f4 p4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) p4[c] = ro_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < RO_NCB; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p4[c] = RO_MFMA(wb[SL][j][c], hf[j][c], p4[c]);
+      const ro_f4 p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+      *reinterpret_cast<ro_f4*>(red + wave * (RO_ROWS * RO_RS) + lrow * RO_RS + 4 * lq) = p;
+      ro_barrier();
+    }
+    // ---- coupling of this subnet -> new state; input rows of the next subnet
+    advance(sm, s + 1 < a.n_sub ? sm + RO_SMALL_WORDS : nullptr, xs + 256 * xcur, xs + 256 * (xcur ^ 1));
+    xcur ^= 1;
+    ro_barrier();
+  }
+  RO_STAMP(33)
+  // ---- FixedLinearTransform rev: (x - b).mm(M_inv); [:, :ndof]; clamp_to_joint_limits
+  if (t < 256) {
+    const int row = t >> 4, j = t & 15;
+    if (j < a.ndof && m0 + row < a.M) {
+      const float* x = xs + 256 * xcur + row * 16;
+      float q = 0.f;
+      for (int k = 0; k < a.D; ++k) {
+        float xv = x[k];
+        if (a.sigmoid) xv = 1.0f / (1.0f + expf(-xv));
+        q = fmaf(xv - a.b_lin[k], a.M_inv[k * a.D + j], q);
+      }
+      if (a.clamp_limits) q = fminf(fmaxf(q, a.lo[j]), a.hi[j]);
+      a.q_out[(size_t)(m0 + row) * a.ndof + j] = q;
+    }
+  }
+  RO_STAMP(34)
+#undef RO_STAMP
+}
+
+// ---- the stream image of one subnet (see the header of this file); one thread per float4
+struct RoPackArgs {
+  SubnetWeights w;
+  float* out;        // 132 groups x 64 KB
+};
+__global__ __launch_bounds__(256) void k_rowowner_pack(RoPackArgs p) {
+  const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;   // float4 index inside the subnet image
+  const int lane = (int)(i4 & 63), cb = (int)((i4 >> 6) & 7), wave = (int)((i4 >> 9) & 7);
+  const int g = (int)(i4 >> 12);
+  if (g >= RO_SUB_GROUPS) return;
+  const int lrow = lane & 15, lq = lane >> 4;
+  const SubnetWeights& w = p.w;
+  ro_f4 v;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = 0.f;
+    if (g == 0) {
+      const int col = wave * 128 + cb * 16 + lrow, k = 4 * lq + c;
+      if (k < w.n_x + 7) x = w.w_first_t[(size_t)k * RO_W + col];
+      else if (k == w.n_x + 7) x = w.w_soft[col];
+      else if (k == 15) x = w.b_first[col];
+    } else if (g == 1 || g == 2 + RO_KG) {
+      x = w.b_mid[g == 1 ? 0 : 1][wave * 128 + cb * 16 + 4 * lq + c];
+    } else if (g < RO_SUB_GROUPS - 1) {
+      const int l = g < 2 + RO_KG ? 0 : 1;
+      const int kg = g - (l == 0 ? 2 : 3 + RO_KG);
+      const int col = wave * 128 + cb * 16 + lrow, k = kg * 16 + 4 * lq + c;
+      x = w.w_mid[l][(size_t)col * RO_W + k];
+    } else {
+      const int o = lrow, k = wave * 128 + cb * 16 + 4 * lq + c;
+      if (o < w.n_out) x = w.w_last[(size_t)o * RO_W + k];
+    }
+    v[c] = x;
+  }
+  reinterpret_cast<ro_f4*>(p.out)[i4] = v;
+}
+
+size_t rowowner_subnet_floats() { return (size_t)RO_SUB_GROUPS * (RO_GROUP_BYTES / 4); }
+const char* rowowner_kernel_name() { return "k_flow_rowowner"; }
+size_t rowowner_stream_floats(int n_sub) { return ((size_t)n_sub * RO_SUB_GROUPS + 4) * (RO_GROUP_BYTES / 4); }  // + ring lead padding
+bool rowowner_shape_ok(const FlowDims& d, int n_sub) {
+  const int nmax = d.L1 > d.L2 ? d.L1 : d.L2;
+  return d.width == RO_W && d.n_hidden == 3 && d.D <= 16 && nmax + 8 <= 15 && 2 * nmax <= 16 && n_sub <= RO_MAX_SUB && d.ndof <= 16;
+}
+hipError_t launch_rowowner_pack(const SubnetWeights& w, float* out, hipStream_t s) {
+  RoPackArgs p{w, out};
+  const size_t n4 = (size_t)RO_SUB_GROUPS * (RO_GROUP_BYTES / 16);
+  hipLaunchKernelGGL(k_rowowner_pack, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+hipError_t launch_flow_rowowner(const RoArgs& a, int nbuf, hipStream_t s) {
+  static bool done4[64] = {}, done2[64] = {};
+  const unsigned grid = (unsigned)((a.M + RO_ROWS - 1) / RO_ROWS);
+  hipError_t e;
+  if (nbuf == 2) {
+    e = ensure_dynamic_lds(k_flow_rowowner<2>, RO_LDS_BYTES, done2);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_rowowner<2>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, a);
+  } else {
+    e = ensure_dynamic_lds(k_flow_rowowner<4>, RO_LDS_BYTES, done4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_rowowner<4>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ikf

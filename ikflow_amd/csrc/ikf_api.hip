@@ -90,6 +90,16 @@ struct ikf_model {
   float* wfrag_arena = nullptr;          // fragment-major images of the hidden Linear weights (small-batch kernel)
   std::vector<const float*> w_mid_frag;  // [subnet][layer], same flattening; null when the width does not fit
 
+  // Row-owner form (flow_rowowner.hip): the whole inverse pass of a batch in ONE launch, a workgroup per 16 rows, weights streamed past
+  // them from `ro_stream` (the subnets' parameters in execution and consumption order, +203 MB for Panda).  Taken for the full rounds of
+  // n_cu x 16 rows of a batch and for a last partial round of at least ro_min_tail rows; the rest runs on the per-layer kernels.
+  //   ro_mode: -1 by batch size, 0 never, 1 always (ikf_set_gemm_variant 180 / 181 / 182)
+  float* ro_stream = nullptr;
+  RoSubnet* d_ro_sub = nullptr;
+  int ro_mode = -1, ro_nbuf = 4;
+  int n_cu = 256;
+  long long ro_min_tail = -1;  // -1: 13/16 of a round
+
   // packed weights (one arena)
   float* arena = nullptr;
   size_t arena_floats = 0;
@@ -237,6 +247,10 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
 
   ikf_model* m = new ikf_model();
   m->device = device;
+  {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0) m->n_cu = n_cu;
+  }
   m->desc = *desc;
   m->dims.D = D;
   m->dims.L1 = D / 2;  // ikflow/model.py:336 (old FrEIA rule)
@@ -291,6 +305,8 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->split_arena) (void)hipFree(m->split_arena);
   if (m->split_frag_arena) (void)hipFree(m->split_frag_arena);
   if (m->wfrag_arena) (void)hipFree(m->wfrag_arena);
+  if (m->ro_stream) (void)hipFree(m->ro_stream);
+  if (m->d_ro_sub) (void)hipFree(m->d_ro_sub);
   if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
   if (m->d_Minv) (void)hipFree(m->d_Minv);
   if (m->d_blin) (void)hipFree(m->d_blin);
@@ -412,6 +428,36 @@ static ikf_status build_frag_weights(ikf_model* m) {
       IKF_HIP(launch_wfrag_pack(m->subnets[si].w_mid[l], W, W, dst, nullptr));
       m->w_mid_frag[(size_t)si * 3 + l] = dst;
     }
+  IKF_HIP(hipDeviceSynchronize());
+  return IKF_OK;
+}
+
+// the row-owner kernel's parameter stream: every subnet's weights in execution order (block NB-1 .. 0, s1 then s2) and, inside a subnet,
+// in the order the kernel consumes them (k_rowowner_pack), plus the small per-subnet table (last-Linear bias, perm_inv, split)
+static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& perm_host) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes, n_sub = 2 * NB;
+  if (m->ro_stream) { (void)hipFree(m->ro_stream); m->ro_stream = nullptr; }
+  if (m->d_ro_sub) { (void)hipFree(m->d_ro_sub); m->d_ro_sub = nullptr; }
+  if (!rowowner_shape_ok(d, n_sub) || d.slope < 0.f || d.slope > 1.f) return IKF_OK;
+  const size_t floats = rowowner_stream_floats(n_sub);
+  if (floats * 4 >= (size_t)1 << 32) return IKF_OK;  // (one 32-bit buffer descriptor)
+  IKF_HIP(hipMalloc(&m->ro_stream, sizeof(float) * floats));
+  IKF_HIP(hipMemset(m->ro_stream, 0, sizeof(float) * floats));
+  IKF_HIP(hipMalloc(&m->d_ro_sub, sizeof(RoSubnet) * n_sub));
+  std::vector<RoSubnet> tab(n_sub);
+  std::vector<float> b_last(16);
+  for (int sidx = 0; sidx < n_sub; ++sidx) {
+    const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
+    const SubnetWeights& w = m->subnets[2 * b + which - 1];
+    IKF_HIP(launch_rowowner_pack(w, m->ro_stream + (size_t)sidx * rowowner_subnet_floats(), nullptr));
+    RoSubnet& r = tab[sidx];
+    memset(&r, 0, sizeof(r));
+    IKF_HIP(hipMemcpy(r.b_last, w.b_last, sizeof(float) * w.n_out, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; ++k) r.perm_inv[k] = k < d.D ? perm_host[(size_t)b * d.D + k] : k;
+    r.which = which; r.n_x = w.n_x; r.x_off = which == 1 ? 0 : d.L1; r.n_half = w.n_out / 2;
+  }
+  IKF_HIP(hipMemcpy(m->d_ro_sub, tab.data(), sizeof(RoSubnet) * n_sub, hipMemcpyHostToDevice));
   IKF_HIP(hipDeviceSynchronize());
   return IKF_OK;
 }
@@ -560,6 +606,8 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
   m->chain_tab_valid = false;  // (the chain's argument table points into the weight arenas)
   ikf_status fst = build_frag_weights(m);
   if (fst != IKF_OK) return fst;
+  fst = build_rowowner_stream(m, perm_host);
+  if (fst != IKF_OK) return fst;
   m->loaded = true;
   if (m->precision == 1) {
     ikf_status sst = build_split_weights(m);  // refusal: precision falls back to f32, the handle stays usable
@@ -648,6 +696,12 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   }
   if (variant >= 130 && variant <= 134) {  // write-through activation stores: none / contractions / entry kernel / both / by batch size
     m->wt_stores = variant == 134 ? -1 : variant - 130;
+    return IKF_OK;
+  }
+  if (variant >= 180 && variant <= 182) {  // row-owner form (one launch per call, rows resident on chip): never / by batch size / always
+    if (variant == 182 && m->loaded && m->ro_stream == nullptr)
+      return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_gemm_variant(182): the row-owner kernel needs coeff_fn_internal_size 1024 and coeff_fn_config 3");
+    m->ro_mode = variant == 180 ? 0 : (variant == 181 ? -1 : 1);
     return IKF_OK;
   }
   if (variant == 170 || variant == 171) {  // <= 128 rows: the whole subnet chain in one launch (XCD-local hand-over): off / on
@@ -993,12 +1047,55 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
   return IKF_OK;
 }
 
+// rows [0, n_ro) of a batch go through the row-owner launch, the rest through the per-layer kernels
+static long long rowowner_rows(const ikf_model* m, long long rows) {
+  if (m->ro_stream == nullptr || m->ro_mode == 0 || m->precision != 0 || !m->loaded) return 0;
+  if (m->ro_mode == 1) return rows;
+  if (m->gemm_variant >= 0 || m->tile_cfg >= 0 || m->fuse_tail != 0) return 0;  // a forced per-layer form is being measured
+  const long long round = (long long)m->n_cu * IKF_RO_ROWS;
+  const long long min_tail = m->ro_min_tail >= 0 ? m->ro_min_tail : round * 13 / 16;
+  const long long full = rows / round * round, rem = rows - full;
+  return full + (rem >= min_tail ? rem : 0);
+}
+extern "C" const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows) {
+  if (m && rows > 0 && 2 * rowowner_rows(m, rows) >= rows) return rowowner_kernel_name();
+  return (m && m->precision == 1 && m->split_arena) ? split_kernel_name() : fused_kernel_name();
+}
+static ikf_status run_flow_rowowner(ikf_model* m, const PoseSource& ps, const float* d_latent, long long rows, int clamp_limits,
+                                    float* d_q_out, hipStream_t s) {
+  const FlowDims& d = m->dims;
+  const long long kMaxLaunchRows = 1LL << 24;
+  for (long long r0 = 0; r0 < rows; r0 += kMaxLaunchRows) {
+    const long long nr = rows - r0 < kMaxLaunchRows ? rows - r0 : kMaxLaunchRows;
+    RoArgs a{};
+    a.stream = m->ro_stream;
+    a.stream_bytes = (unsigned)(rowowner_stream_floats(2 * m->desc.nb_nodes) * sizeof(float));
+    a.sub = m->d_ro_sub; a.n_sub = 2 * m->desc.nb_nodes;
+    a.x0 = d_latent + (size_t)r0 * d.D;
+    a.ps = ps; a.row0 = r0; a.M = (int)nr; a.D = d.D; a.L1 = d.L1; a.ndof = d.ndof; a.clamp = d.clamp; a.slope = d.slope;
+    a.M_inv = m->d_Minv; a.b_lin = m->d_blin; a.lo = chain_lo(m); a.hi = chain_hi(m);
+    a.clamp_limits = clamp_limits; a.sigmoid = m->desc.sigmoid_on_output ? 1 : 0;
+    a.q_out = d_q_out + (size_t)r0 * d.ndof;
+    a.trace = nullptr;
+    IKF_HIP(prof_mark(m, s));
+    IKF_HIP(launch_flow_rowowner(a, m->ro_nbuf, s));
+    IKF_HIP(prof_mark(m, s));
+  }
+  return IKF_OK;
+}
+
 static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
                            float* d_q_out, hipStream_t s) {
-  ikf_status st = ensure_scratch(m, rows);
+  const long long n_ro = rowowner_rows(m, rows);
+  ikf_status st = IKF_OK;
+  if (n_ro > 0) {
+    st = run_flow_rowowner(m, ps, d_latent, n_ro, clamp_limits, d_q_out, s);
+    if (st != IKF_OK || n_ro == rows) return st;
+  }
+  st = ensure_scratch(m, rows - n_ro);
   if (st != IKF_OK) return st;
   const bool fused = fused_ok(m);
-  for (long long r0 = 0; r0 < rows; r0 += m->chunk_rows) {
+  for (long long r0 = n_ro; r0 < rows; r0 += m->chunk_rows) {
     const long long nr = (rows - r0 < m->chunk_rows) ? rows - r0 : m->chunk_rows;
     st = fused ? run_flow_chunk_fused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s)
                : run_flow_chunk_unfused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s);

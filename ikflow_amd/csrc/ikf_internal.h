@@ -201,6 +201,41 @@ extern int g_entry_geom_override;  // probes: force an entry-kernel geometry
 hipError_t launch_flow_finalize(const FinalizeArgs& a, hipStream_t s);
 const char* fused_kernel_name();
 
+// flow_rowowner.hip - the whole inverse pass in ONE launch: a workgroup keeps its 16 rows on chip through every subnet and streams
+// the weights past them (width 1024, coeff_fn_config 3).  No scratch, no inter-workgroup synchronisation.
+struct RoSubnet {          // one executed subnet (execution order): what is not in the stream
+  float b_last[16];
+  int perm_inv[16];        // which == 2: new_state[d] = cat[perm_inv[d]] (PermuteRandom rev); identity otherwise
+  int which, n_x, x_off, n_half;   // n_half = n_out / 2 state elements rewritten, starting at (which == 1 ? L1 : 0)
+};
+
+struct RoArgs {
+  const float* stream;     // [n_sub][132][8 waves][8 blocks][64 lanes][4], + PF groups of padding
+  unsigned stream_bytes;
+  const RoSubnet* sub;
+  int n_sub;
+  const float* x0;         // [M][D] latent rows of this chunk
+  PoseSource ps;
+  long long row0;
+  int M, D, L1, ndof;
+  float clamp, slope;
+  const float* M_inv;      // [D][D]
+  const float* b_lin;      // [D]
+  const float* lo;
+  const float* hi;
+  int clamp_limits, sigmoid;
+  float* q_out;            // [M][ndof]
+  unsigned long long* trace;   // probes: [grid][64] shader-clock stamps, or null
+};
+
+constexpr int IKF_RO_ROWS = 16;                       // rows per workgroup
+size_t rowowner_subnet_floats();                        // floats of one subnet's stream image
+size_t rowowner_stream_floats(int n_sub);               // whole image incl. the ring's lead padding
+bool rowowner_shape_ok(const FlowDims& d, int n_sub);
+hipError_t launch_rowowner_pack(const SubnetWeights& w, float* out, hipStream_t s);
+hipError_t launch_flow_rowowner(const RoArgs& a, int nbuf, hipStream_t s);
+const char* rowowner_kernel_name();
+
 // flow_split.hip - the hidden contraction on the f16 matrix cores with an error-compensated operand split:
 //   a = hi + lo/2048,  hi = f16(a),  lo = f16((a - hi) * 2048)        (same for the weights, split once at load)
 //   a.w ~= hi_a*hi_w + (hi_a*lo_w + lo_a*hi_w)/2048                    (3 v_mfma_f32_32x32x16_f16, fp32 accumulate)

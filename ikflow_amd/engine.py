@@ -403,7 +403,10 @@ class Engine:
         self.last_event_overhead_ms = float(self.lib.ikf_profile_event_overhead_ms(self._h))
         return int(n.value), float(ms.value)
 
-    def dominant_kernel_name(self) -> str:
+    def dominant_kernel_name(self, rows: Optional[int] = None) -> str:
+        """Name (as in a rocprofv3 kernel trace) of the kernel that carries a batch of `rows` rows; None: the per-layer contraction."""
+        if rows is not None:
+            return self.lib.ikf_dominant_kernel_for(self._h, int(rows)).decode()
         if self.precision == "f16x3":
             return self.lib.ikf_split_kernel_name().decode()
         return self.lib.ikf_dominant_kernel_name().decode()

@@ -244,6 +244,9 @@ int ikf_split_overflow_pending(ikf_model* m, void* stream);
 const char* ikf_split_kernel_name(void);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
 const char* ikf_dominant_kernel_name(void);
+/* ... of the kernel that carries (most of) a batch of `rows` rows on this handle with its current settings: "k_flow_rowowner" for
+ * batches that take the one-launch row-owner form, else the per-layer contraction of the selected precision. */
+const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
 /* Select the flow pipeline (a tuning / test switch; every setting computes the same function):
  *   -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly, 101..108 the fused form with tile
  *   configuration 0..7 forced, 160 with the 16 x 32 small-batch tiles forced; 0..8 the unfused 4-kernel form with that tile variant;
@@ -255,6 +258,9 @@ const char* ikf_dominant_kernel_name(void);
  *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced
  *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced
  *   170 / 171        <= 128 rows: the whole subnet chain in one launch, hand-over between layers inside each XCD: off (default) / on
+ *   180 / 181 / 182  row-owner form (ONE launch per call; a workgroup keeps 16 rows on chip through every subnet, weights streamed
+ *                    past them; width 1024, coeff_fn_config 3): never / by batch size (default: full rounds of CUs x 16 rows and a
+ *                    last partial round of >= 13/16 of one) / always
  * Returns IKF_ERR_BAD_ARGUMENT if unknown. */
 ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 

@@ -212,11 +212,16 @@ def test_full_batch_properties_4096():
     for lo, hi in [(0, 1), (5, 133), (4000, 4096), (1024, 1536), (0, 2048)]:
         part = s.generate_ik_solutions(P[lo:hi].contiguous(), n=(1 if hi - lo == 1 else None), latent=L[lo:hi].contiguous())
         assert (part - full[lo:hi]).abs().max().item() <= FLOW_TOL
-    s.engine(DEV).set_gemm_variant(101)  # pin the 128x128 tile configuration: now bitwise
-    for lo, hi in [(0, 1), (5, 133), (4000, 4096)]:
-        part = s.generate_ik_solutions(P[lo:hi].contiguous(), n=(1 if hi - lo == 1 else None), latent=L[lo:hi].contiguous())
-        assert torch.equal(part, full[lo:hi])
+    # pin one form for every size: now bitwise - the 128x128 per-layer tiles (101), then the row-owner launch (182)
+    for variant in (101, 182):
+        s.engine(DEV).set_gemm_variant(variant)
+        pinned = s.generate_ik_solutions(P, latent=L)
+        assert (pinned - full).abs().max().item() <= FLOW_TOL
+        for lo, hi in [(0, 1), (5, 133), (4000, 4096)]:
+            part = s.generate_ik_solutions(P[lo:hi].contiguous(), n=(1 if hi - lo == 1 else None), latent=L[lo:hi].contiguous())
+            assert torch.equal(part, pinned[lo:hi]), (variant, lo, hi)
     s.engine(DEV).set_gemm_variant(-1)
+    s.engine(DEV).set_gemm_variant(181)
     # oracle on a slice
     ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses[:256], lat[:256])
     assert (full[:256].cpu() - ref).abs().max().item() <= FLOW_TOL
@@ -1321,6 +1326,85 @@ def test_small_batch_one_launch_form_equals_two_launches(kw):
     # (rounds of <= 128 rows take the 16-row head: seeds equal to rounding, refined to the same solutions)
     assert torch.equal(res[0][1], res[1][1]) and (res[0][0] - res[1][0]).abs().max().item() <= 1e-3
     eng.set_gemm_variant(111)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(nb_nodes=3, dim=7, n_hidden=3, width=1024),                                    # the released Panda shape (L1 = 3, L2 = 4)
+    dict(nb_nodes=2, dim=10, n_hidden=3, width=1024, robot_name="fetch_arm"),           # FetchArm's (L1 = L2 = 5: 13 first-Linear inputs)
+    dict(nb_nodes=2, dim=8, n_hidden=3, width=1024, robot_name="fetch"),                # Fetch's (8 dof)
+    dict(nb_nodes=2, dim=7, n_hidden=3, width=1000),                                    # a width the engine pads to 1024
+    dict(nb_nodes=2, dim=7, n_hidden=3, width=1024, softflow=False, sigmoid=True),      # sigmoid_on_output graph, 7-entry conditional
+])
+def test_row_owner_form_matches_oracle_and_the_per_layer_kernels(kw):
+    """k_flow_rowowner (one launch per call: a workgroup keeps 16 rows on chip through every subnet, weights streamed past them) forced
+    for every batch (ikf_set_gemm_variant 182) against the oracle and against the per-layer kernels (180): ragged row counts on both
+    sides of the 16-row workgroup boundary, more than one round of 256 workgroups, the single-pose broadcast, a non-zero softflow
+    entry, unclamped outputs, and the exact path's tile-major pose gather.  Another summation order than the per-layer kernels:
+    equal to rounding, each within 1e-5 of the oracle."""
+    robot, hp, lay, sd = custom_model(seed=21, gain=1.5, **kw)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n_max = 4096 + 37
+    _, poses = reachable_poses(robot, n_max, 131)
+    lat = latents(n_max, lay.dim, 132)
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
+    for n in (1, 15, 16, 17, 100, 1000, n_max):
+        P, L = poses[:n].to(DEV), lat[:n].to(DEV)
+        kw_n = dict(n=(1 if n == 1 else None), latent=L, clamp_to_joint_limits=False)
+        eng.set_gemm_variant(182)
+        ro = s.generate_ik_solutions(P, **kw_n)
+        assert torch.equal(ro, s.generate_ik_solutions(P, **kw_n)), "the same bits every time"
+        eng.set_gemm_variant(180)
+        layered = s.generate_ik_solutions(P, **kw_n)
+        scale = torch.clamp(ref[:n].abs(), min=1.0)
+        err = ((ro.cpu() - ref[:n]).abs() / scale).max().item()
+        dif = ((ro - layered).cpu().abs() / scale).max().item()
+        assert err <= FLOW_TOL, f"{kw} n={n}: {err:.2e} from the oracle"
+        assert dif <= FLOW_TOL, f"{kw} n={n}: {dif:.2e} from the per-layer kernels"
+    eng.set_gemm_variant(182)
+    # clamped (the API default) and the single-pose form y.expand(n, 7)
+    n = 333
+    got = s.generate_ik_solutions(poses[5].to(DEV), n=n, latent=lat[:n].to(DEV)).cpu()
+    want = fo.generate_ik_solutions_torch(sd, lay, robot, poses[5:6].expand(n, 7), lat[:n], clamp=True)
+    assert (got - want).abs().max().item() <= FLOW_TOL
+    if lay.dim_cond == 8:
+        cond = torch.cat([poses[:100], torch.full((100, 1), 0.4)], dim=1)
+        got = eng.generate_approx(poses[:100].to(DEV), lat[:100].to(DEV), False, softflow_scale=0.4).cpu()
+        assert (got - fo.run_inference_torch(sd, lay, robot, lat[:100], cond, False)).abs().max().item() <= 10 * FLOW_TOL
+    # exact IK: the retry rounds' flow rows (poses gathered through the active-pose list, tile-major repeats) through the row-owner launch
+    res = []
+    for variant in (180, 182):
+        eng.set_gemm_variant(variant)
+        torch.manual_seed(5)
+        res.append(s.generate_exact_ik_solutions(poses[:100].to(DEV), pos_error_threshold=0.05, rot_error_threshold=0.5))
+    assert torch.equal(res[0][1], res[1][1]) and (res[0][0] - res[1][0]).abs().max().item() <= 1e-3
+    eng.set_gemm_variant(181)
+
+
+def test_row_owner_form_is_what_the_baseline_batch_runs():
+    """By default a batch's full rounds of (CUs x 16) rows and a last partial round of >= 13/16 of one take the row-owner launch, the
+    rest the per-layer kernels: 4096 rows = one launch, 4096 + 200 = one launch + a 200-row per-layer chunk; results are those of the
+    forced forms row for row (identical bits with the form that ran them)."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 4096 + 200
+    _, poses = reachable_poses(robot, n, 7)
+    lat = latents(n, lay.dim, 8)
+    P, L = poses.to(DEV), lat.to(DEV)
+    eng.set_gemm_variant(182)
+    ro = s.generate_ik_solutions(P, latent=L)
+    eng.set_gemm_variant(180)
+    layered_tail = s.generate_ik_solutions(P[4096:], latent=L[4096:])
+    eng.set_gemm_variant(181)
+    auto = s.generate_ik_solutions(P, latent=L)
+    assert torch.equal(auto[:4096], ro[:4096])
+    assert torch.equal(auto[4096:], layered_tail)
+    eng.profile_begin()
+    s.generate_ik_solutions(P[:4096], latent=L[:4096])
+    n_launch, _ = eng.profile_end()
+    assert n_launch == 1, "4096 rows = one row-owner launch"
+    assert "rowowner" in eng.dominant_kernel_name(4096) and "gemm" in eng.dominant_kernel_name(512)
 
 
 @pytest.mark.parametrize("kw", [
