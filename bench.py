@@ -315,7 +315,7 @@ def cpu_baseline_exact(sd, layout, robot_name, poses_cpu, threads, pos_thr, rot_
 # ---------------------------------------------------------------------------------------------------------------------
 # committed profile figures shown beside the live ones
 # ---------------------------------------------------------------------------------------------------------------------
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(kernel_substr="k_flow_gemm<"):
     """HBM bytes per dominant-kernel launch from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_summary.json:
     separate FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 x2 read correction applied). PMC counters
     cannot be collected from inside the process, so this is the recorded figure, or None if no summary is present."""
@@ -326,7 +326,10 @@ def pmc_traffic_per_launch():
         return None, None
     try:
         with open(files[-1]) as f:
-            return json.load(f).get("dominant_kernel_traffic_bytes_per_launch"), os.path.basename(files[-1])
+            d = json.load(f)
+        if kernel_substr.rstrip("<") not in str(d.get("dominant_kernel", "k_flow_gemm")):
+            return None, None  # the newest committed summary is of another dominant kernel
+        return d.get("dominant_kernel_traffic_bytes_per_launch"), os.path.basename(files[-1])
     except Exception:
         return None, None
 
@@ -599,33 +602,46 @@ def main():
         assert rccl["gathered_shards_ok"], "a gathered shard does not carry its rank's checksum"
         assert rccl["world_size"] == world
 
-    # dominant kernel: per-launch HIP-event timing (on the engine's stream) of every hidden-Linear contraction inside
-    # a few more, otherwise identical, steps
+    # dominant kernel: per-launch HIP-event timing (on the engine's stream) inside a few more, otherwise identical, steps.
+    #   row-owner form (k_flow_rowowner: the whole inverse pass of the batch in ONE launch - what B = 4096 runs): algorithmic FLOP per
+    #     launch = rows of the launch x SURVEY 8(d)'s 101,572,608 FLOP per solution (every Linear of every subnet);
+    #   per-layer form (k_flow_gemm: one hidden Linear of all rows per launch): 2 x rows x width^2.
+    dom_kernel = eng.dominant_kernel_name(B)
+    row_owner = "rowowner" in dom_kernel
+    eng.profile_begin()  # (a throw-away pass first: the event pool's first allocations stay out of the measured pairs)
+    stepper.step()
+    eng.profile_end()
     eng.profile_begin()
     gemm_layers = 2 * layout.nb_nodes * (layout.n_hidden - 1)
-    chunks = (B + 16383) // 16384  # the engine processes a call in chunks of <= 16384 rows
-    prof_steps = max(1, min(10, max(2, args.steps), 8000 // (gemm_layers * chunks)))  # the event pool holds 8192 pairs
+    chunks = (B + 16383) // 16384  # the per-layer engine processes a call in chunks of <= 16384 rows
+    launches_per_step = 1 if row_owner else gemm_layers * chunks
+    prof_steps = max(1, min(10, max(2, args.steps), 8000 // launches_per_step))  # the event pool holds 8192 pairs
     for _ in range(prof_steps):
         stepper.step()
     n_launch, tot_ms = eng.profile_end()
     gemm_ms = tot_ms / max(n_launch, 1)
-    # every hidden layer processes all B rows of a step, in one launch (B <= 16384) or in 16384-row chunks
-    flop_per_launch = prof_steps * gemm_layers * 2.0 * B * layout.width * layout.width / max(n_launch, 1)
+    if row_owner:
+        # (a batch that is not a whole number of rounds also runs a per-layer tail: its launches are timed too - count the work they did)
+        flop_per_launch = prof_steps * float(B) * layout.flops_per_solution() / max(n_launch, 1)
+    else:
+        # every hidden layer processes all B rows of a step, in one launch (B <= 16384) or in 16384-row chunks
+        flop_per_launch = prof_steps * gemm_layers * 2.0 * B * layout.width * layout.width / max(n_launch, 1)
     achieved = flop_per_launch / (gemm_ms * 1e-3) / 1e12
     value = world * B * args.steps / elapsed
     flow_tflops = value / world * layout.flops_per_solution() / 1e12
 
     headline_cfg = args.batch == 4096 and args.model == MODEL and args.precision == "f32"
-    traffic, traffic_src = pmc_traffic_per_launch() if headline_cfg else (None, None)
-    prof_us, prof_src = rocprof_kernel_avg_us() if headline_cfg else (None, None)
+    ksub = "k_flow_rowowner" if row_owner else "k_flow_gemm<"
+    traffic, traffic_src = pmc_traffic_per_launch(ksub) if headline_cfg else (None, None)
+    prof_us, prof_src = rocprof_kernel_avg_us(ksub) if headline_cfg else (None, None)
     live = {"traffic": None, "avg_us": None, "note": "not run"}
     if not args.no_live_pmc and headline_cfg and world == 1:
-        live = live_profile()
+        live = live_profile(ksub)
     live_traffic, live_note = live["traffic"], live["note"]
     if live["avg_us"] is not None:
         prof_us, prof_src = live["avg_us"], "rocprofv3 --kernel-trace --stats in this run"
     extra = {"flow_tflops_per_gpu": round(flow_tflops, 2), "frac_of_fp32_mfma_peak_end_to_end": round(flow_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-             "gemm_ms": round(gemm_ms, 5), "gemm_launches_per_step": gemm_layers}
+             "gemm_ms": round(gemm_ms, 5), "gemm_launches_per_step": launches_per_step}
     if args.precision == "f32" and not args.no_split_extra:
         # the same workload with the hidden contractions on the error-compensated 3x f16 MFMA split (opt-in precision mode;
         # measured closer to the fp64 twin than the f32 MFMA path - tests/test_gpu_parity.py::test_flow_f16_split_*).
@@ -701,7 +717,7 @@ def main():
                      "traffic_unit": "HBM bytes per launch",
                      "traffic_source": live_note if live_traffic is not None else traffic_src,
                      "traffic_committed": traffic, "traffic_committed_source": traffic_src, "traffic_live_note": live_note,
-                     "kernel": eng.dominant_kernel_name(),
+                     "kernel": dom_kernel,
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms,
                      "timing": f"hipEvent pair per launch on the engine stream, {n_launch} launches over extra steps; an empty pair "
                                f"({eng.last_event_overhead_ms * 1e3:.2f} us, calibrated on the same stream) is subtracted",

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
   const int lrow = lane & 15, lq = lane >> 4;
 #define RO_STAMP(i) if (a.trace != nullptr && t == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
   RO_STAMP(0)
+  const unsigned long long ro_t0_wall = a.trace != nullptr ? wall_clock64() : 0ull;
 
   // ---- the weight stream: ring of NBUF slots x 8 float4 per lane
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.stream), 0, a.stream_bytes, 0x00020000);
@@ -195,6 +196,8 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
   for (int s = 0; s < a.n_sub; ++s) {
     const float* sm = small + s * RO_SMALL_WORDS;
     RO_STAMP(1 + (s < 31 ? s : 31))
+#define RO_PHASE(i) if (s == 2) { RO_STAMP(40 + (i)) }
+    RO_PHASE(0)
     // ---- group 0 (slot 0): first Linear + LeakyReLU -> tile0
     {
       RO_ISSUE(PF % NBUF)
@@ -208,9 +211,12 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
       RO_EPILOGUE(tile0)
       ro_barrier();
     }
+    RO_PHASE(1)
     // ---- groups 1..65: hidden Linear 2 (tile0 -> tile1); groups 66..130: hidden Linear 3 (tile1 -> tile0)
     RO_LAYER(1 % NBUF, tile0, tile1)
+    RO_PHASE(2)
     RO_LAYER(66 % NBUF, tile1, tile0)
+    RO_PHASE(3)
     // ---- group 131: last Linear, this wave's 128-k slice; partial sums [row][16 outputs] -> red[wave]
     {
       RO_ISSUE((131 + PF) % NBUF)
@@ -229,10 +235,12 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
       *reinterpret_cast<ro_f4*>(red + wave * (RO_ROWS * RO_RS) + lrow * RO_RS + 4 * lq) = p;
       ro_barrier();
     }
+    RO_PHASE(4)
     // ---- coupling of this subnet -> new state; input rows of the next subnet
     advance(sm, s + 1 < a.n_sub ? sm + RO_SMALL_WORDS : nullptr, xs + 256 * xcur, xs + 256 * (xcur ^ 1));
     xcur ^= 1;
     ro_barrier();
+    RO_PHASE(5)
   }
   RO_STAMP(33)
   // ---- FixedLinearTransform rev: (x - b).mm(M_inv); [:, :ndof]; clamp_to_joint_limits
@@ -251,6 +259,10 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
     }
   }
   RO_STAMP(34)
+  if (a.trace != nullptr && t == 0) {  // probes: the constant 100 MHz clock beside the shader clock (effective GHz of this launch)
+    a.trace[(size_t)blockIdx.x * 64 + 36] = wall_clock64();
+    a.trace[(size_t)blockIdx.x * 64 + 35] = ro_t0_wall;
+  }
 #undef RO_STAMP
 }
 

@@ -166,9 +166,23 @@ int main(int argc, char** argv) {
   ms /= iters;
   const double flop = 2.0 * M * (double)n_sub * 2 * W * W;
   printf("%.4f ms per call = %.3f M rows/s; hidden contractions alone %.1f TFLOP/s (%.3f of 157.3)\n", ms, M / ms * 1e-3, flop / ms * 1e-9, flop / ms * 1e-9 / 157.3);
+  {  // the same launches, each bracketed by its own event pair (what ikf_profile_begin/_end does)
+    std::vector<hipEvent_t> ev(2 * iters);
+    for (auto& e : ev) CK(hipEventCreate(&e));
+    for (int i = 0; i < iters; ++i) {
+      CK(hipEventRecord(ev[2 * i], nullptr));
+      CK(launch_flow_rowowner(a, nbuf, nullptr));
+      CK(hipEventRecord(ev[2 * i + 1], nullptr));
+    }
+    CK(hipDeviceSynchronize());
+    double sum = 0, span = 0;
+    for (int i = 0; i < iters; ++i) { float m1; CK(hipEventElapsedTime(&m1, ev[2 * i], ev[2 * i + 1])); sum += m1; }
+    { float m1; CK(hipEventElapsedTime(&m1, ev[0], ev[2 * iters - 1])); span = m1; }
+    printf("per-launch event pairs: mean %.4f ms per launch; first event -> last event %.4f ms per launch\n", sum / iters, span / iters);
+  }
   // in-kernel timeline
   a.trace = d_trace;
-  CK(launch_flow_rowowner(a, nbuf, nullptr));
+  for (int i = 0; i < 3; ++i) CK(launch_flow_rowowner(a, nbuf, nullptr));
   CK(hipDeviceSynchronize());
   std::vector<unsigned long long> tr((size_t)grid * 64);
   CK(hipMemcpy(tr.data(), d_trace, tr.size() * 8, hipMemcpyDeviceToHost));
@@ -187,5 +201,31 @@ int main(int argc, char** argv) {
   auto mn = [](const std::vector<double>& v) { return v.empty() ? 0.0 : *std::min_element(v.begin(), v.end()); };
   printf("cycles per subnet: median %.0f min %.0f max %.0f (matrix-pipe floor 2 x 131072 + 2 x 2048 = 266240); per workgroup total: median %.0f max %.0f; start skew max %.0f\n",
          med(per_sub), mn(per_sub), mx(per_sub), med(total), mx(total), mx(start));
+  {
+    const unsigned long long* p0 = &tr[0];
+    const double us = (double)(p0[36] - p0[35]) / 100.0;  // 100 MHz constant clock
+    printf("workgroup 0 of the last of three back-to-back traced launches: %.1f us, %.0f shader cycles -> %.3f GHz\n", us, (double)(p0[34] - p0[0]), (double)(p0[34] - p0[0]) / us * 1e-3);
+  }
+  if (grid >= 8) {  // workgroup b runs on XCD b % 8 (observed placement): wall time and effective clock per XCD
+    unsigned long long w0 = ~0ull, w1 = 0;
+    for (unsigned b = 0; b < grid; ++b) { w0 = std::min(w0, tr[(size_t)b * 64 + 35]); w1 = std::max(w1, tr[(size_t)b * 64 + 36]); }
+    printf("first workgroup start -> last workgroup end: %.1f us\n", (double)(w1 - w0) / 100.0);
+    for (int x = 0; x < 8; ++x) {
+      double us = 0, cyc = 0, st = 0, en = 0; int n = 0;
+      for (unsigned b = x; b < grid && b < 256; b += 8) {
+        const unsigned long long* p = &tr[(size_t)b * 64];
+        us += (double)(p[36] - p[35]) / 100.0; cyc += (double)(p[34] - p[0]); st += (double)(p[35] - w0) / 100.0; en += (double)(p[36] - w0) / 100.0; ++n;
+      }
+      printf("  XCD %d: %d workgroups, mean %.1f us, %.3f GHz, mean start +%.1f us, mean end +%.1f us\n", x, n, us / n, cyc / us * 1e-3, st / n, en / n);
+    }
+  }
+  if (n_sub > 2) {
+    const char* names[5] = {"first Linear", "hidden 2", "hidden 3", "last Linear", "coupling + next input rows"};
+    for (int ph = 0; ph < 5; ++ph) {
+      std::vector<double> v;
+      for (unsigned b = 0; b < grid; ++b) v.push_back((double)(tr[(size_t)b * 64 + 41 + ph] - tr[(size_t)b * 64 + 40 + ph]));
+      printf("  phase %-28s median %8.0f max %8.0f cycles\n", names[ph], med(v), mx(v));
+    }
+  }
   return max_err < 2e-5 ? 0 : 2;
 }
