@@ -347,7 +347,7 @@ def live_profile(kernel_substr="k_flow_gemm<"):
     import subprocess
     import tempfile
 
-    out = {"traffic": None, "avg_us": None, "note": ""}
+    out = {"traffic": None, "avg_us": None, "note": "", "occupancy_waves_per_simd": None, "mfma_busy_frac_of_launch": None}
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         out["note"] = "rocprofv3 not found"
@@ -375,6 +375,26 @@ def live_profile(kernel_substr="k_flow_gemm<"):
             finally:
                 shutil.rmtree(d, ignore_errors=True)
         out["traffic"] = int(2 * per_counter["FETCH_SIZE"] + per_counter["WRITE_SIZE"])
+        # achieved occupancy and matrix-pipe busy fraction (tools/pmc_summarize.py: SQ_WAVE_CYCLES counts quad-cycles over the chip,
+        # GRBM_GUI_ACTIVE cycles per XCD summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES cycles over the 1024 SIMDs)
+        try:
+            d = run(["--pmc", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "--kernel-trace"])
+            try:
+                acc = {}
+                for r in csv.DictReader(open(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0])):
+                    if kernel_substr in r["Kernel_Name"] and "skinny" not in r["Kernel_Name"]:
+                        key = (r["Dispatch_Id"], r["Counter_Name"])
+                        acc[key] = acc.get(key, 0.0) + float(r["Counter_Value"])
+                disp = sorted({k[0] for k in acc})
+                mean = lambda c: sum(acc.get((i, c), 0.0) for i in disp) / max(len(disp), 1)
+                gui = mean("GRBM_GUI_ACTIVE") / 8.0
+                if gui > 0:
+                    out["occupancy_waves_per_simd"] = 4.0 * mean("SQ_WAVE_CYCLES") / (gui * 1024.0)
+                    out["mfma_busy_frac_of_launch"] = mean("SQ_VALU_MFMA_BUSY_CYCLES") / 1024.0 / gui
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+        except Exception:
+            pass
         d = run(["--kernel-trace", "--stats"], steps="20", warmup="5")  # 1200 launches, like tools/profile_round.sh
         try:
             calls, total = 0, 0.0
@@ -500,9 +520,43 @@ def cell_exact_converged(solver, eng, robot, layout, B, dev, reps, seed, pos_thr
                     "the flow output of random weights is not used as the seed"}
 
 
+def committed_call_traffic(tag):
+    """Fabric-side bytes one generate_ik_solutions call moves, from the newest committed rocprofv3 PMC summary of that batch size
+    (profiles/rNN_pmc_summary_<tag>.json: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction): the flow kernels' mean
+    bytes per dispatch x their dispatches, divided by the calls in the pass (one k_flow_finalize per call).  (None, None) if absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_summary_{tag}.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            ks = json.load(f)["kernels"]
+        flow = {k: v for k, v in ks.items() if k.startswith("ikf::k_") and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v
+                and not any(x in k for x in ("pack", "k_fk", "k_clamp", "k_pose", "k_lm", "k_exact", "k_compact"))}
+        calls = sum(v["dispatches"] for k, v in flow.items() if "k_flow_finalize" in k)
+        if not calls:
+            return None, None
+        tot = sum((v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]) * v["dispatches"] for v in flow.values())
+        return tot / calls, os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
+def _with_counters(cell, tag):
+    b, src = committed_call_traffic(tag)
+    if b is not None:
+        gbps = b / (cell["ms_per_call"] * 1e-3) / 1e9
+        cell["hbm_bytes_per_call_counters"] = int(b)
+        cell["hbm_GBps_counters"] = round(gbps, 1)
+        cell["frac_of_hbm_peak_8TBps_counters"] = round(gbps / 8000.0, 4)
+        cell["counters_source"] = f"profiles/{src} (FETCH_SIZE x 2 + WRITE_SIZE of the call's flow kernels: fabric-side, Infinity-Cache hits included) over this run's ms_per_call"
+    return cell
+
+
 def run_cells(solver, eng, robot, layout, dev, precision):
     cells = {}
-    cells["approx_B512"] = cell_approx(solver, robot, layout, 512, dev, 100, 5)
+    cells["approx_B512"] = _with_counters(cell_approx(solver, robot, layout, 512, dev, 100, 5), "b512")
     # BASELINE config 1's shape (batch 16) and the reference harnesses' regime (tens of solutions per pose): the only cells where the
     # HBM roofline binds - one pass streams every weight once (203 MB) whatever the batch
     for b in (16, 128):
@@ -510,7 +564,7 @@ def run_cells(solver, eng, robot, layout, dev, precision):
         gbps = layout.weight_bytes() / (c["ms_per_call"] * 1e-3) / 1e9
         c["weight_stream_GBps"] = round(gbps, 1)
         c["frac_of_hbm_peak_8TBps"] = round(gbps / 8000.0, 4)
-        cells[f"approx_B{b}"] = c
+        cells[f"approx_B{b}"] = _with_counters(c, f"b{b}")
     cells["exact_B4096_worst_case"] = cell_exact(solver, eng, robot, layout, 4096, dev, 5, 6)
     cells["exact_B512_worst_case"] = cell_exact(solver, eng, robot, layout, 512, dev, 10, 7)
     cells["exact_B4096_converged_case"] = cell_exact_converged(solver, eng, robot, layout, 4096, dev, 20, 8)
@@ -634,7 +688,7 @@ def main():
     ksub = "k_flow_rowowner" if row_owner else "k_flow_gemm<"
     traffic, traffic_src = pmc_traffic_per_launch(ksub) if headline_cfg else (None, None)
     prof_us, prof_src = rocprof_kernel_avg_us(ksub) if headline_cfg else (None, None)
-    live = {"traffic": None, "avg_us": None, "note": "not run"}
+    live = {"traffic": None, "avg_us": None, "note": "not run", "occupancy_waves_per_simd": None, "mfma_busy_frac_of_launch": None}
     if not args.no_live_pmc and headline_cfg and world == 1:
         live = live_profile(ksub)
     live_traffic, live_note = live["traffic"], live["note"]
@@ -721,6 +775,14 @@ def main():
                      "flop_per_launch": flop_per_launch, "avg_launch_ms": gemm_ms,
                      "timing": f"hipEvent pair per launch on the engine stream, {n_launch} launches over extra steps; an empty pair "
                                f"({eng.last_event_overhead_ms * 1e3:.2f} us, calibrated on the same stream) is subtracted",
+                     "occupancy": {
+                         # launch geometry: 512-thread workgroups, one per CU (row-owner: 146 KB of LDS; per-layer 128x128 tiles: 110 KB)
+                         "waves_per_simd_launch_geometry": 2.0, "of_max_waves_per_simd": 8,
+                         "waves_per_simd_achieved": live.get("occupancy_waves_per_simd"),
+                         "mfma_busy_frac_of_launch": live.get("mfma_busy_frac_of_launch"),
+                         "source": "rocprofv3 --pmc SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES in this run: 4 x SQ_WAVE_CYCLES / "
+                                   "(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), time-averaged over the launch (profiled clock); committed twin: "
+                                   "profiles/rNN_pmc_summary.json"},
                      "rocprof_avg_launch_us": prof_us, "rocprof_source": prof_src,
                      "frac_rocprof": (flop_per_launch / (prof_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if prof_us else None},
         "extra": extra,
