@@ -143,6 +143,47 @@ def timed_steps(stepper, steps, warmup):
     return elapsed, sol
 
 
+def asked_global_batch(mode, world, rows, global_batch):
+    """Poses per step the job was ASKED for: the strong modes split a fixed batch with ceil(G / world) rows per rank, so up to world - 1
+    padding rows are computed but never asked for - they count neither in `value` nor in config.global_batch."""
+    if mode == "million":
+        return 1_000_000
+    if mode == "strong":
+        return global_batch
+    return world * rows
+
+
+def gpu_numa_affinity(dev, pin):
+    """NUMA node / CPU list of the GPU behind `dev` from sysfs (PCI domain:bus:device.0), and - pin=True - this process pinned to those
+    CPUs (os.sched_setaffinity): 8 rank processes on a 2-socket host each enqueue ~50 launches per step at 4.3 us of host time a launch,
+    and a rank scheduled on the far socket pays for it.  Never raises; the record goes into the line's `rccl.ranks[*]`."""
+    rec = {"numa_node": None, "cpus": None, "pinned": False}
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        bdf = f"{int(getattr(props, 'pci_domain_id', 0)):04x}:{int(props.pci_bus_id):02x}:{int(props.pci_device_id):02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        rec["pci"] = bdf
+        with open(base + "/numa_node") as f:
+            rec["numa_node"] = int(f.read().strip())
+        with open(base + "/local_cpulist") as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        rec["cpus"] = len(allowed)
+        if pin and allowed and rec["numa_node"] is not None and rec["numa_node"] >= 0:
+            os.sched_setaffinity(0, allowed)
+            rec["pinned"] = True
+    except Exception as e:
+        rec["note"] = f"not available ({type(e).__name__})"
+    return rec
+
+
 def rows_per_rank(mode, world, batch, global_batch):
     """Rows one rank processes per step: weak = --batch per GPU; strong = ceil(global batch / world); million = ceil(1e6 / world)."""
     if mode == "million":
@@ -152,7 +193,7 @@ def rows_per_rank(mode, world, batch, global_batch):
     return batch
 
 
-def collective_proof(stepper, sol, rank, world, local_rank, dev):
+def collective_proof(stepper, sol, rank, world, local_rank, dev, affinity=None, kernel_ms=None):
     """What makes an N>1 line self-proving: the process group's backend and size as torch.distributed reports them, the RCCL
     version, one record per rank (device index, name, uuid / PCI bus id - N distinct GPUs), every rank's own elapsed time,
     and a check of the LAST gathered tensor on every rank: the own shard sits bit-for-bit at the rank offset AND every other
@@ -172,6 +213,10 @@ def collective_proof(stepper, sol, rank, world, local_rank, dev):
     times = torch.empty(world, dtype=torch.float64, device=sol.device)
     dist.all_gather_into_tensor(times, torch.tensor([stepper.local_elapsed], dtype=torch.float64, device=sol.device))
     me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+    if affinity is not None:
+        me["affinity"] = affinity
+    if kernel_ms is not None:
+        me["dominant_kernel_ms"] = kernel_ms
     if torch.device(dev).type == "cuda":
         props = torch.cuda.get_device_properties(dev)
         me.update(device=str(dev), name=props.name, uuid=str(getattr(props, "uuid", "")), pci_bus_id=getattr(props, "pci_bus_id", None))
@@ -191,6 +236,10 @@ def collective_proof(stepper, sol, rank, world, local_rank, dev):
             "gathered_shards_ok": bool(flag.item() == 1),
             "rank_elapsed_ms_min": min(t_ms), "rank_elapsed_ms_max": max(t_ms),
             "distinct_devices": len({(r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in ranks}),
+            # a throttled or badly placed GPU shows here: the dominant kernel's event-timed launch duration per rank
+            "rank_kernel_ms_min": min((r["dominant_kernel_ms"] for r in ranks if r.get("dominant_kernel_ms") is not None), default=None),
+            "rank_kernel_ms_max": max((r["dominant_kernel_ms"] for r in ranks if r.get("dominant_kernel_ms") is not None), default=None),
+            "ranks_pinned_to_gpu_numa_node": sum(1 for r in ranks if (r.get("affinity") or {}).get("pinned")),
             "ranks": ranks}
 
 
@@ -312,6 +361,34 @@ def cpu_baseline_exact(sd, layout, robot_name, poses_cpu, threads, pos_thr, rot_
                       f"repeat_counts {rc}, {rows[0]} flow rows, {dt:.1f} s"}
 
 
+def exact_distance_to_fp32_loop(eng, robot, robot_name, B, dev, seed, pos_thr=1e-3, rot_thr=0.01):
+    """How far the exact-IK results sit from the REFERENCE-precision loop (ikflow_solver.py:199-211: jrl solves each LM step in fp32;
+    the HIP kernel solves it in fp64): the converged-case inputs of cell_exact_converged through ikf_refine_exact and through the
+    oracle's round with its default fp32 LM step and with the fp64 one.  Oracle = checker (CPU-baseline leg), not the measured path."""
+    from oracle import kinematics_oracle as ko
+
+    rng = np.random.default_rng(seed)
+    q_true = torch.tensor(robot.sample_joint_angles(B, EPS_LIMITS, rng), device=dev)
+    poses = robot.forward_kinematics(q_true)
+    seeds = robot.clamp_to_joint_limits(q_true + 0.05 * torch.randn(B, robot.ndof, generator=torch.Generator().manual_seed(seed)).to(dev))
+    sol, valid = eng.refine_exact(poses, seeds, 1, pos_thr, rot_thr)
+    sol, valid = sol.cpu(), valid.cpu()
+    s32, v32 = ko.exact_round(robot_name, seeds.cpu(), poses.cpu(), 1, pos_thr, rot_thr)
+    s64, v64 = ko.exact_round(robot_name, seeds.cpu(), poses.cpu(), 1, pos_thr, rot_thr, lm_dtype=torch.float64)
+
+    def dist(a, b, m):
+        d = (a[m] - b[m]).abs().max(1).values
+        return {"median": float(d.median()), "p99": float(d.quantile(0.99)), "max": float(d.max()), "poses": int(m.sum())}
+
+    return {"flags_agree_with_fp32_loop": float((valid == v32).float().mean()),
+            "abs_dq_hip_vs_fp32_loop": dist(sol, s32, valid & v32),
+            "abs_dq_fp64_twin_vs_fp32_loop": dist(s64, s32, v64 & v32),
+            "abs_dq_hip_vs_fp64_twin": dist(sol, s64, valid & v64),
+            "note": f"{B} poses, seeds q_true + N(0, 0.05^2), thresholds {pos_thr} m / {rot_thr} rad, one round of <= 3 LM steps; rad, max over "
+                    "the joints of a pose, over poses valid on both sides.  The kernel evaluates the LM step in fp64 (DESIGN 5): its "
+                    "distance to the fp32 loop is that loop's own fp32-solve noise (the fp64 twin shows the same distance)"}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # committed profile figures shown beside the live ones
 # ---------------------------------------------------------------------------------------------------------------------
@@ -359,7 +436,7 @@ def live_profile(kernel_substr="k_flow_gemm<"):
         d = tempfile.mkdtemp(prefix="ikf_prof_", dir="/tmp")
         sub[3], sub[5] = steps, warmup
         subprocess.run([exe] + flags + ["-d", d, "-o", "p", "--output-format", "csv", "--"] + sub, cwd="/tmp",
-                       env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
+                       env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
         return d
 
     per_counter = {}
@@ -395,7 +472,8 @@ def live_profile(kernel_substr="k_flow_gemm<"):
                 shutil.rmtree(d, ignore_errors=True)
         except Exception:
             pass
-        d = run(["--kernel-trace", "--stats"], steps="20", warmup="5")  # 1200 launches, like tools/profile_round.sh
+        # (200 steps: the clock ramp behind each idle gap of the sub-run - ~10 slow launches - stays a percent of the average)
+        d = run(["--kernel-trace", "--stats"], steps="200" if "rowowner" in kernel_substr else "20", warmup="10" if "rowowner" in kernel_substr else "5")
         try:
             calls, total = 0, 0.0
             for r in csv.DictReader(open(glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)[0])):
@@ -406,7 +484,7 @@ def live_profile(kernel_substr="k_flow_gemm<"):
         finally:
             shutil.rmtree(d, ignore_errors=True)
         out["note"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; traffic = 2 x FETCH_SIZE + "
-                       "WRITE_SIZE) over a 4-step sub-run and --kernel-trace --stats over a 25-step sub-run of the same workload")
+                       "WRITE_SIZE) over a 4-step sub-run and --kernel-trace --stats over a longer sub-run of the same workload")
     except Exception as e:  # never let the profiler leg take the bench line down
         out["note"] = f"rocprofv3 leg failed ({type(e).__name__}); committed profile figures reported instead"
     return out
@@ -611,11 +689,15 @@ def main():
             local_rank = 0
             dist.init_process_group(TEST_BACKEND)
         else:
+            assert torch.cuda.device_count() > local_rank, (
+                f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible - one rank per GPU: check "
+                f"--nproc-per-node against HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (={os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', 'unset'))})")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    affinity = gpu_numa_affinity(dev, pin=use_dist and not TEST_BACKEND and os.environ.get("IKF_BENCH_NO_PIN") is None)
 
     from ikflow_amd.ikflow_solver import IKFlowSolver
     from ikflow_amd.model import MODEL_DESCRIPTIONS, hparams_for, layout_from, random_state_dict
@@ -652,9 +734,6 @@ def main():
     rccl = None
     if use_dist:
         assert torch.equal(stepper.last_gathered()[rank * B : (rank + 1) * B], sol)  # own shard sits at its rank offset
-        rccl = collective_proof(stepper, sol, rank, world, local_rank, dev)
-        assert rccl["gathered_shards_ok"], "a gathered shard does not carry its rank's checksum"
-        assert rccl["world_size"] == world
 
     # dominant kernel: per-launch HIP-event timing (on the engine's stream) inside a few more, otherwise identical, steps.
     #   row-owner form (k_flow_rowowner: the whole inverse pass of the batch in ONE launch - what B = 4096 runs): algorithmic FLOP per
@@ -665,6 +744,11 @@ def main():
     eng.profile_begin()  # (a throw-away pass first: the event pool's first allocations stay out of the measured pairs)
     stepper.step()
     eng.profile_end()
+    # ... and no idle gap in front of the measured pairs: the chip drops its clocks within ~10 ms of idling and needs ~10 launches
+    # (30 ms) to come back - the first launch behind a gap takes 3.5 ms instead of 2.8 (tools/launch_timing_check.py).  The warm steps
+    # and the bracketed steps are enqueued back to back; profile_begin() itself touches nothing on the device.
+    for _ in range(0 if args.steps < 3 else 15):
+        stepper.step()
     eng.profile_begin()
     gemm_layers = 2 * layout.nb_nodes * (layout.n_hidden - 1)
     chunks = (B + 16383) // 16384  # the per-layer engine processes a call in chunks of <= 16384 rows
@@ -681,7 +765,14 @@ def main():
         # every hidden layer processes all B rows of a step, in one launch (B <= 16384) or in 16384-row chunks
         flop_per_launch = prof_steps * gemm_layers * 2.0 * B * layout.width * layout.width / max(n_launch, 1)
     achieved = flop_per_launch / (gemm_ms * 1e-3) / 1e12
-    value = world * B * args.steps / elapsed
+    if use_dist:
+        # (after the event-timed steps: every rank's dominant-kernel launch time rides in the proof; same inputs, same bits as `sol`)
+        stepper.fence()
+        rccl = collective_proof(stepper, sol, rank, world, local_rank, dev, affinity=affinity, kernel_ms=gemm_ms)
+        assert rccl["gathered_shards_ok"], "a gathered shard does not carry its rank's checksum"
+        assert rccl["world_size"] == world
+    asked = asked_global_batch(mode, world, B, args.global_batch)  # strong modes: ceil(G / world) rows per rank, the padding is not counted
+    value = asked * args.steps / elapsed
     flow_tflops = value / world * layout.flops_per_solution() / 1e12
 
     headline_cfg = args.batch == 4096 and args.model == MODEL and args.precision == "f32"
@@ -713,11 +804,11 @@ def main():
         eng.set_split_guard(True)
         solver.set_precision("f32")
         extra["f16x3_split"] = {
-            "value": world * B * n2 / dt2, "unit": "IK solutions/s", "ms_per_step": 1000.0 * dt2 / n2,
+            "value": asked * n2 / dt2, "unit": "IK solutions/s", "ms_per_step": 1000.0 * dt2 / n2,
             "kernel": "k_split_gemm_dma", "avg_launch_ms": ms2 / max(nl2, 1),
             "range_guard": "on: per call one 4-byte overflow-flag read (stream sync) and an f32 re-run if set",
             "f32_reruns": eng.split_fallback_count,
-            "value_guard_off": world * B * n2 / dt3, "overflow_flag_after_guard_off_run": bool(pending),
+            "value_guard_off": asked * n2 / dt3, "overflow_flag_after_guard_off_run": bool(pending),
             "max_abs_diff_vs_f32_path": float((sol2 - sol).abs().max().item()),
             "note": "opt-in IKFlowSolver.set_precision('f16x3'): a = hi + lo/2048 operand split, 3 v_mfma_f32_32x32x16_f16 per 16 k, fp32 accumulate",
             "bound": "power",
@@ -735,8 +826,10 @@ def main():
             _, _, st2 = workload(rows)
             dt, s2 = timed_steps(st2, st, wu)
             proof = collective_proof(st2, s2, rank, world, local_rank, dev)
-            extra["scaling_modes"][name] = {"value": world * rows * st / dt, "unit": "IK solutions/s", "ms_per_step": 1e3 * dt / st, "steps": st,
-                                            "warmup": wu, "rows_per_rank": rows, "global_batch": world * rows, "scaling": "strong",
+            asked2 = asked_global_batch(m2, world, rows, g2)
+            extra["scaling_modes"][name] = {"value": asked2 * st / dt, "unit": "IK solutions/s", "ms_per_step": 1e3 * dt / st, "steps": st,
+                                            "warmup": wu, "rows_per_rank": rows, "global_batch": asked2, "padded_rows": world * rows - asked2,
+                                            "scaling": "strong",
                                             "gathered_shards_ok": proof["gathered_shards_ok"],
                                             "rank_elapsed_ms_min": proof["rank_elapsed_ms_min"], "rank_elapsed_ms_max": proof["rank_elapsed_ms_max"]}
             del st2
@@ -764,7 +857,7 @@ def main():
         "config": {"workload": f"{args.model} generate_ik_solutions, B={B} poses per GPU per step, clamp_to_joint_limits"
                                + (" (1,000,000 poses per step over all ranks)" if args.million else "")
                                + (f" (fixed global batch of {args.global_batch} poses per step split over the ranks)" if mode == "strong" else ""),
-                   "global_batch": world * B, "scaling_mode": mode,
+                   "global_batch": asked, "rows_per_rank": B, "padded_rows": world * B - asked, "scaling_mode": mode,
                    "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": live_traffic if live_traffic is not None else traffic,
@@ -808,6 +901,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, layout, name, poses.cpu(), latent.cpu(), args.cpu_seconds)
             if not args.no_cells and not args.million:
                 out["cpu_baseline"]["exact_ik"] = cpu_baseline_exact(sd, layout, name, poses[:2048].cpu(), out["cpu_baseline"]["cores"], 1e-3, 0.01)
+                for b_, seed_ in ((4096, 8), (512, 9)):  # the seeds of the converged-case cells
+                    cell = out["extra"].get("cells", {}).get(f"exact_B{b_}_converged_case")
+                    if cell is not None:
+                        cell["distance_to_fp32_lm_loop"] = exact_distance_to_fp32_loop(eng, robot, name, b_, dev, seed_)
         print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist
@@ -846,7 +943,8 @@ def dry_run(args, world, rank, use_dist):
     if rank == 0:
         print(json.dumps({"dry_run": True, "metric": "DRY RUN (gloo, CPU tensors, stand-in compute): no throughput claim", "value": None,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathered_ok": ok,
-                          "scaling": "weak" if mode == "weak" else "strong", "global_batch": world * B, "rows_per_rank": B,
+                          "scaling": "weak" if mode == "weak" else "strong", "global_batch": asked_global_batch(mode, world, B, args.global_batch),
+                          "padded_rows": world * B - asked_global_batch(mode, world, B, args.global_batch), "rows_per_rank": B,
                           "ms_per_step": 1000.0 * elapsed / max(args.steps, 1), "rccl": proof}), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -72,28 +72,46 @@ def test_sharded_rows_gloo(world, n):
 
 # ---- bench.py's own multi-rank plumbing (env handling, process group, ShardedStepper step / fence / gather, max over
 # ranks, the one JSON line) under gloo on CPU tensors, launched exactly as the driver launches it ------------------------
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("extra", [[], ["--million"], ["--global-batch", "4097"]])
-def test_bench_dry_run_under_torch_distributed_run(extra):
+def test_bench_dry_run_under_torch_distributed_run(extra, world):
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
            "--batch", "257", "--dist-dry-run"] + extra
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=root)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 prints ONE JSON line
     out = json.loads(lines[0])
-    assert out["dry_run"] is True and out["value"] is None and out["n_gpus"] == 2 and out["gathered_ok"] is True
+    assert out["dry_run"] is True and out["value"] is None and out["n_gpus"] == world and out["gathered_ok"] is True
     assert out["scaling"] == ("strong" if extra else "weak")
-    assert out["global_batch"] == (1_000_000 if extra == ["--million"] else 4098 if extra else 514)  # ceil(4097 / 2) rows per rank
-    rc = out["rccl"]  # the self-proof every multi-rank line carries (here: gloo, two CPU processes)
-    assert rc["backend"] == "gloo" and rc["world_size"] == 2 and rc["gathered_shards_ok"] is True and not rc["is_rccl"]
-    assert [r["rank"] for r in rc["ranks"]] == [0, 1] and len({r["pid"] for r in rc["ranks"]}) == 2
+    # strong modes: ceil(G / world) rows per rank; the line reports the batch that was ASKED for and the padding beside it
+    per_rank = (1_000_000 + world - 1) // world if extra == ["--million"] else ((4097 + world - 1) // world if extra else 257)
+    asked = 1_000_000 if extra == ["--million"] else (4097 if extra else world * 257)
+    assert out["rows_per_rank"] == per_rank and out["global_batch"] == asked and out["padded_rows"] == world * per_rank - asked
+    rc = out["rccl"]  # the self-proof every multi-rank line carries (here: gloo, CPU processes)
+    assert rc["backend"] == "gloo" and rc["world_size"] == world and rc["gathered_shards_ok"] is True and not rc["is_rccl"]
+    assert [r["rank"] for r in rc["ranks"]] == list(range(world)) and len({r["pid"] for r in rc["ranks"]}) == world
     assert 0 < rc["rank_elapsed_ms_min"] <= rc["rank_elapsed_ms_max"]
+
+
+def test_bench_refuses_more_ranks_than_visible_gpus_with_a_message_naming_the_variable():
+    """LOCAL_RANK beyond the visible GPUs (a launch with --nproc-per-node above HIP_VISIBLE_DEVICES) must fail with a message that says so,
+    not with a HIP error from set_device; and the NUMA-affinity record never raises, whatever sysfs offers."""
+    import bench
+
+    rec = bench.gpu_numa_affinity("cpu", pin=False)
+    assert rec["pinned"] is False and "note" in rec
+    src = open(bench.__file__).read()
+    assert "HIP_VISIBLE_DEVICES" in src and "torch.cuda.device_count() > local_rank" in src
+    assert bench.asked_global_batch("strong", 8, 513, 4097) == 4097 and bench.asked_global_batch("weak", 8, 4096, 0) == 32768
+    assert bench.asked_global_batch("million", 8, 125000, 0) == 1_000_000
 
 
 class _FakeSolver:

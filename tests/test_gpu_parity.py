@@ -846,6 +846,24 @@ def test_exact_ik_seeded_is_row_exact_against_the_oracle(which, pos_thr, rot_thr
     assert int(stats[0, 0]) == n and int(valid.sum()) == int(stats[:, 3].sum())
     # per-round bookkeeping agrees with the oracle's up to the band poses
     assert abs(int(stats[:, 3].sum()) - n_ref[0]) <= int(band.sum())
+    # ... and how far that sits from the REFERENCE-precision loop (ikflow_solver.py:199-211: jrl solves the step in fp32; the kernel
+    # and the oracle above solve it in fp64): flags, and the distribution of |q_hip - q_cpu32| on poses valid on both sides, next to
+    # the fp32 loop's own distance from the fp64 loop.  fp32 normal equations at cond(J^T J) ~ 1e5 make the fp32 loop the noisy one:
+    # the HIP result must be no further from it than it is from its own fp64 twin.
+    ref32_sol, ref32_valid = ko.generate_exact_ik_solutions_seeded(robot, seed_cpu, poses, rc, pos_thr, rot_thr)
+    agree = float((valid == ref32_valid).float().mean())
+    agree_twins = float((ref_valid == ref32_valid).float().mean())
+
+    def dist(a, b, m):
+        d_ = (a[m] - b[m]).abs().max(1).values
+        return float(d_.median()), float(d_.quantile(0.99)), float(d_.max())
+
+    d32 = dist(sol, ref32_sol, valid & ref32_valid)
+    o32 = dist(ref_sol, ref32_sol, ref_valid & ref32_valid)
+    print(f"   vs the fp32-LM loop: flags agree {agree:.4f} (fp64 twin vs fp32 loop {agree_twins:.4f}); |q_hip - q_cpu32| median {d32[0]:.2e} "
+          f"p99 {d32[1]:.2e} max {d32[2]:.2e}; |q_f64 - q_cpu32| median {o32[0]:.2e} p99 {o32[1]:.2e} max {o32[2]:.2e}")
+    assert agree >= 0.95 and agree >= agree_twins - 0.005
+    assert d32[0] <= 1.5 * o32[0] + 1e-6 and d32[1] <= 1.5 * o32[1] + 1e-5
 
 
 def _random_exact_configs(count, seed):

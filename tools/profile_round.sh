@@ -12,9 +12,11 @@ cd /tmp && export TMPDIR=/tmp
 COMMON="--no-cpu-baseline --no-split-extra --no-cells --no-live-pmc"
 SQSET="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 # kernel-trace statistics: the default workload (B = 4096: the row-owner launch), the same batch on the per-layer kernels, and the other cells
+# (200 steps: behind every idle gap the chip needs ~10 launches / 30 ms to come back to its clock - tools/launch_timing_check.py -
+# and a run has three such gaps; with 200 steps they stay a percent of the row-owner launch's average)
 for V in "default:" "per_layer:--gemm-variant 180" "b512:--batch 512" "b128:--batch 128" "f16x3:--precision f16x3"; do
   TAG=${V%%:*}; FLAGS=${V#*:}
-  rocprofv3 --kernel-trace --stats -d /tmp/kt_${R}_$TAG -o kt --output-format csv -- python $REPO/bench.py --steps 20 --warmup 5 $COMMON $FLAGS > "$OUT/kt_$TAG.log" 2>&1
+  rocprofv3 --kernel-trace --stats -d /tmp/kt_${R}_$TAG -o kt --output-format csv -- python $REPO/bench.py --steps 200 --warmup 10 $COMMON $FLAGS > "$OUT/kt_$TAG.log" 2>&1
   NAME=bench_${TAG}_kernel_stats.csv; [ "$TAG" = default ] && NAME=bench_kernel_stats.csv
   cp "$(find /tmp/kt_${R}_$TAG -name '*kernel_stats.csv' | head -1)" "$OUT/$NAME"
 done
