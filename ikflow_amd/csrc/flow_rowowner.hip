@@ -93,6 +93,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
   float* const red = smem + RO_OFF_RED;
   float* const cond = smem + RO_OFF_COND;
   float* const small = smem + RO_OFF_SMALL;
+  if (a.run_if != nullptr && __hip_atomic_load(a.run_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;   // (uniform)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m0 = blockIdx.x * RO_ROWS;
@@ -266,6 +267,356 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
 #undef RO_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cluster form for batches that cannot fill the chip with one workgroup per 16 rows (<= 2048 rows): the 16 rows of a row tile are owned by
+// G workgroups (G = 2, 4, 8; workgroup b = member b % G of row tile b / G - with the observed placement b -> XCD b % 8 the members of a
+// tile sit on different XCDs, so every XCD's L2 pulls only its members' column slices of W).  Member j computes columns [j 1024/G,
+// (j+1) 1024/G) of every hidden layer from the FULL 16 x 1024 input tile in its LDS, streaming only its slice of W (same image, same
+// register ring - never drained by a barrier or an exchange).  The first Linear (13 inputs) is evaluated in full by every member - cheaper
+// than exchanging it.  Per subnet the members exchange two things through global memory:
+//   the h2 (hidden 2) slices -> all-gather into every member's input tile of hidden 3;
+//   the last Linear's [16 x 16] partial sums over the member's own h3 columns -> all-gather, summed in member order (h3 never leaves).
+// Hand-over of h2 (cdna_hip_programming.md Guideline 16, form R1): payload as 16-byte write-through (sc1) stores, every storing wave
+// drains, barrier, ONE lane stores the member's epoch word (agent scope); consumers poll the G - 1 epoch words from one wave (relaxed
+// agent-scope loads + s_sleep, bounded), barrier, read the payload with sc1 loads (L1-bypassing; the producer stored sc1, so no acquire
+// fence).  The partial sums (1 KB per member) go the same way with 4-byte sc1 stores and loads.  (Priced and dropped: the partial sums as
+// 8-byte {epoch, value} granules that four waves re-read until every tag matches - 9.0 k cycles per subnet against 5.1 k with the epoch
+// word at 512 rows: behind the CU's own weight stream a re-read pass costs a full round trip, and the first pass usually comes too early.)
+// A hidden layer starts on its OWN slice of the k range (it is already in LDS) and waits for the peers only then: k runs in the rotated
+// order j, j+1, .. (mod G) - a fixed order per output column, so results are reproducible bit for bit, and equal to the row-owner form's
+// to rounding.  Placement-independent; needs all workgroups resident (grid <= CUs, one per CU: the launcher checks); a wait that runs out
+// sets the abort word (every other wait ends) and the host-visible give-up word.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr unsigned kClusterSpinLimit = 1u << 18;   // polls of (s_sleep 1 + one L2-missing load): some 0.1 s - a peer that is not resident
+
+template <int G>
+__global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
+  constexpr int NCB = RO_NCB / G;          // 16-column blocks per wave
+  constexpr int NBUF = 2 * G;              // ring slots of NCB float4: 16 float4 per lane in every form
+  constexpr int PF = NBUF - 1;
+  constexpr int N1 = RO_KG / G;            // 16-k groups of one member's slice
+  constexpr int CS = RO_W / G;             // columns per member
+  static_assert(RO_KG % NBUF == 0, "ring length must divide a layer");
+  const RoArgs& a = c.ro;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const tile0 = smem + RO_OFF_TILE0;
+  float* const tile1 = smem + RO_OFF_TILE1;
+  float* const xs = smem + RO_OFF_XS;
+  float* const us = smem + RO_OFF_US;
+  float* const red = smem + RO_OFF_RED;      // [8][16][20] per-wave partial sums; afterwards [16][20] the subnet's summed outputs
+  float* const cond = smem + RO_OFF_COND;
+  float* const small = smem + RO_OFF_SMALL;
+  __shared__ unsigned s_ok;
+  __shared__ float s_sum[RO_ROWS * RO_RS];   // the pending subnet's summed last-Linear outputs (bias included)
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int j = blockIdx.x % G, rt = blockIdx.x / G;
+  if (t == 0) s_ok = 1;
+  const int m0 = rt * RO_ROWS;
+  const int lrow = lane & 15, lq = lane >> 4;
+#define RC_STAMP(i) if (a.trace != nullptr && t == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
+  RC_STAMP(0)
+  const unsigned long long t0_wall = a.trace != nullptr ? wall_clock64() : 0ull;
+
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.stream), 0, a.stream_bytes, 0x00020000);
+  const unsigned cbg0 = (unsigned)j * (64 / G) + (unsigned)wave * NCB;   // first 16-column (16-k) block of this wave
+  const unsigned voff = cbg0 * 1024 + lane * 16;
+  const int n_hl = 2 * a.n_sub;             // hidden layers of the call
+  // byte offset of the stream group that holds k group i (in this member's rotated order) of hidden layer hl
+  auto grp = [&](int hl, int i) -> unsigned {
+    hl = hl < n_hl ? hl : n_hl - 1;
+    const unsigned g = (unsigned)(hl >> 1) * RO_SUB_GROUPS + ((hl & 1) ? 3 + RO_KG : 2) + (unsigned)((j * N1 + i) & (RO_KG - 1));
+    return g * RO_GROUP_BYTES;
+  };
+  ro_f4 wb[NBUF][NCB];
+#define RC_ISSUE(slot, hl_, i_)                                                                                                    \
+  {                                                                                                                                \
+    const unsigned so_ = __builtin_amdgcn_readfirstlane(grp((hl_), (i_)));                                                         \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_)                                                                          \
+        wb[slot][cb_] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cb_ * 1024, so_, 0));           \
+  }
+  // a subnet's small groups (first Linear, the two hidden biases, last Linear): this wave's NCB blocks of each
+  auto small_load = [&](int sub, int g, ro_f4 (&dst)[NCB]) {
+    sub = sub < a.n_sub ? sub : a.n_sub - 1;
+    const unsigned so = __builtin_amdgcn_readfirstlane(((unsigned)sub * RO_SUB_GROUPS + (unsigned)g) * RO_GROUP_BYTES);
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) dst[cb] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + cb * 1024, so, 0));
+  };
+  // the first Linear in full: this wave's 128 TRUE columns [128 wave, 128 wave + 128) of group 0 (the row-owner form's operand)
+  ro_f4 w1[RO_NCB];
+  auto w1_load = [&](int sub) {
+    sub = sub < a.n_sub ? sub : a.n_sub - 1;
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)sub * RO_SUB_GROUPS * RO_GROUP_BYTES + (unsigned)wave * RO_WAVE_GROUP_BYTES);
+#pragma unroll
+    for (int cb = 0; cb < RO_NCB; ++cb) w1[cb] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(lane * 16 + cb * 1024), so, 0));
+  };
+  ro_f4 b2[NCB], b3[NCB], wl[NCB];
+  w1_load(0);
+#pragma unroll
+  for (int s = 0; s < PF; ++s) RC_ISSUE(s, 0, s)
+
+  // exchange buffers of this row tile
+  // (h2 of subnet s + 1 may overwrite h2 of subnet s: a member publishes it only after it has seen every peer's partial sums of subnet s,
+  // which a peer publishes after it has read the h2 tile of subnet s)
+  float* const X1 = c.xbuf + (size_t)rt * RO_ROWS * RO_W;                                // h2 [16][1024], true column order
+  float* const P = c.pbuf + (size_t)rt * G * 256;                                        // [G][16][16]
+  unsigned* const flags = c.flags + (size_t)rt * G * 32;
+  const __amdgpu_buffer_rsrc_t rsX1 = __builtin_amdgcn_make_buffer_rsrc(X1, 0, RO_ROWS * RO_W * 4, 0x00020000);
+
+  // ---- rows: state, conditional, per-subnet small parameters -> LDS (every member holds the whole state)
+  if (t < 256) {
+    const int row = t >> 4, d = t & 15;
+    int gr = m0 + row;
+    gr = gr < a.M ? gr : a.M - 1;
+    xs[row * 16 + d] = d < a.D ? a.x0[(size_t)gr * a.D + d] : 0.f;
+  } else if (t < 256 + 128) {
+    const int row = (t - 256) >> 3, k = t & 7;
+    int gr = m0 + row;
+    gr = gr < a.M ? gr : a.M - 1;
+    const long long grow = a.row0 + gr;
+    const long long pm = grow < a.ps.n_mod ? grow : (a.ps.n_mod == 1 ? 0 : grow % a.ps.n_mod);
+    const long long pi = a.ps.idx ? (long long)a.ps.idx[pm] : pm;
+    cond[row * 8 + k] = k < 7 ? a.ps.poses[pi * a.ps.stride + k] : a.ps.softflow;
+  }
+  for (int i = t; i < a.n_sub * RO_SMALL_WORDS; i += RO_WAVES * 64) small[i] = reinterpret_cast<const float*>(a.sub)[i];
+  ro_barrier();
+
+  // new state (threads 0..255) and the next subnet's input rows (threads 256..511) from the pending subnet's summed outputs in s_sum
+  auto new_state = [&](const float* sm, const float* xs_old, int row, int d) -> float {
+    if (sm == nullptr) return xs_old[row * 16 + d];
+    const int* smi = reinterpret_cast<const int*>(sm);
+    const int which = smi[32], nl = smi[35];
+    const int src = which == 2 ? smi[16 + d] : d;
+    const int off = which == 1 ? a.L1 : 0;
+    float v = xs_old[row * 16 + src];
+    if (src >= off && src < off + nl) {
+      const int jj = src - off;
+      const float s_cl = a.clamp * (0.636f * atanf(s_sum[row * RO_RS + jj]));
+      v = (v - s_sum[row * RO_RS + nl + jj]) * expf(-s_cl);
+    }
+    return v;
+  };
+  auto advance = [&](const float* pend_sm, const float* nxt_sm, const float* xs_old, float* xs_new) {
+    if (t < 256) {
+      const int row = t >> 4, d = t & 15;
+      if (d < a.D) xs_new[row * 16 + d] = new_state(pend_sm, xs_old, row, d);
+    } else if (nxt_sm != nullptr) {
+      const int row = (t - 256) >> 4, k = t & 15;
+      const int* ni = reinterpret_cast<const int*>(nxt_sm);
+      const int n_x = ni[33], x_off = ni[34];
+      float v = 0.f;
+      if (k < n_x) v = new_state(pend_sm, xs_old, row, x_off + k);
+      else if (k < n_x + 8) v = cond[row * 8 + (k - n_x)];
+      else if (k == 15) v = 1.0f;
+      us[row * RO_US + k] = v;
+    }
+  };
+  advance(nullptr, small, xs, xs + 256);
+  ro_barrier();
+  int xcur = 1;
+
+  // ---- hand-over primitives
+  // this workgroup's payload stores are issued: drain them (every storing wave), then ONE lane publishes the epoch
+#define RC_PUBLISH(e_)                                                                                     \
+  {                                                                                                        \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
+    ro_barrier();                                                                                          \
+    if (t == 0) __hip_atomic_store(flags + j * 32, (unsigned)(e_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+  }
+  // every peer has published epoch e_ (one wave polls, lane p watches member p); false = a wait ran out / somebody aborted
+  auto wait_peers = [&](unsigned e) -> bool {
+    if (wave == 0) {
+      unsigned ok = 1;
+      if (lane < G && lane != j) {
+        unsigned n = 0;
+        while (__hip_atomic_load(flags + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+          __builtin_amdgcn_s_sleep(1);
+          if ((++n & 63u) == 0 && (n > kClusterSpinLimit || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            ok = 0;
+            break;
+          }
+        }
+      }
+      ok = __all(ok != 0) ? 1u : 0u;
+      if (lane == 0) {
+        if (!ok) {
+          __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        s_ok = ok;
+      }
+    }
+    ro_barrier();
+    return s_ok != 0;
+  };
+  // the peers' column slices of an exchanged activation -> this workgroup's LDS tile
+  auto gather = [&](const __amdgpu_buffer_rsrc_t& rsX, float* tile) {
+    constexpr int PER = RO_ROWS * CS / 4 / (RO_WAVES * 64);   // float4 per thread per peer (8 / G)
+    ro_f4 v[G - 1][PER];
+#pragma unroll
+    for (int m = 1; m < G; ++m) {
+      const int p = (j + m) % G;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = t + q * (RO_WAVES * 64), row = idx / (CS / 4), c4 = idx % (CS / 4);
+        v[m - 1][q] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)((row * RO_W + p * CS + c4 * 4) * 4), 0, /*sc1*/ 16));
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < G; ++m) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = t + q * (RO_WAVES * 64), row = idx / (CS / 4), c4 = idx % (CS / 4);
+        *reinterpret_cast<ro_f4*>(tile + row * RO_LDA + m * CS + c4 * 4) = v[m - 1][q];   // member-relative column order
+      }
+    }
+    ro_barrier();
+  };
+
+  ro_f4 acc[NCB];
+  ro_f4 af[2];
+  // LeakyReLU of the accumulators -> own columns of the LDS tile, and (PUB) write-through to the row tile's exchange buffer
+#define RC_EPILOGUE(tile_out, PUB, rsX)                                                                                  \
+  _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) {                                                                \
+    ro_f4 v_ = acc[cb_];                                                                                                 \
+    v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                    \
+    const int col_ = (int)(cbg0 + cb_) * 16 + 4 * lq;                                                                    \
+    *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + (wave * NCB + cb_) * 16 + 4 * lq) = v_;                       \
+    if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((lrow * RO_W + col_) * 4), 0, /*sc1*/ 16); \
+  }
+  // (the LDS tiles hold the columns in MEMBER-RELATIVE order - own slice first, then members j+1, j+2, .. - so the rotated k order is the
+  // ascending physical order and every LDS offset of the layer is a compile-time constant)
+#define RC_AFRAG(tile_in, i_) *reinterpret_cast<const ro_f4*>((tile_in) + lrow * RO_LDA + (i_) * 16 + 4 * lq)
+  // a hidden layer, fully unrolled: k groups in the member's rotated order - its own slice first, the peers' after the hand-over
+#define RC_LAYER(hl_, bias_, tile_in, rsXin, e_in, WAIT)                                                                 \
+  {                                                                                                                      \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = bias_[cb_];                                         \
+    af[0] = RC_AFRAG(tile_in, 0);                                                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < RO_KG; ++i_) {                                                               \
+      if (WAIT && i_ == N1) {                                                                                            \
+        if (!wait_peers(e_in)) return;                                                                                   \
+        gather(rsXin, tile_in);                                                                                          \
+        af[i_ & 1] = RC_AFRAG(tile_in, i_);                                                                              \
+      }                                                                                                                  \
+      RC_ISSUE((i_ + PF) % NBUF, (hl_) + ((i_ + PF) >> 6), (i_ + PF) & (RO_KG - 1))                                      \
+      if (i_ + 1 < RO_KG && !(WAIT && i_ + 1 == N1)) af[(i_ + 1) & 1] = RC_AFRAG(tile_in, i_ + 1);                       \
+      _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                                   \
+          _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = RO_MFMA(wb[i_ % NBUF][cb_][c_], af[i_ & 1][c_], acc[cb_]); \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                 \
+      _Pragma("unroll") for (int q_ = 0; q_ < NCB; ++q_) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                               \
+      }                                                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }                                                                                                                    \
+  }
+
+  for (int s = 0; s < a.n_sub; ++s) {
+    const float* sm = small + s * RO_SMALL_WORDS;
+    const unsigned e0 = (unsigned)s;   // epochs of this subnet's two exchanges: 2 s + 1 (h2), 2 s + 2 (partial sums)
+    RC_STAMP(1 + (s < 31 ? s : 31))
+#define RC_PHASE(i) if (s == 2) { RC_STAMP(40 + (i)) }
+    RC_PHASE(0)
+    small_load(s, 1, b2);
+    small_load(s, 2 + RO_KG, b3);
+    small_load(s, RO_SUB_GROUPS - 1, wl);
+    // ---- first Linear + LeakyReLU, ALL 1024 columns (every member repeats it: 32 MFMAs per wave against an exchange) -> tile0,
+    //      stored in member-relative column order
+    {
+      const ro_f4 uf = *reinterpret_cast<const ro_f4*>(us + lrow * RO_US + 4 * lq);
+      ro_f4 a1[RO_NCB];
+#pragma unroll
+      for (int cb = 0; cb < RO_NCB; ++cb) a1[cb] = ro_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int cb = 0; cb < RO_NCB; ++cb) a1[cb] = RO_MFMA(w1[cb][cc], uf[cc], a1[cb]);
+#pragma unroll
+      for (int cb = 0; cb < RO_NCB; ++cb) {
+        ro_f4 v = a1[cb];
+        v = __builtin_elementwise_max(v, v * a.slope);
+        const int pb = (wave * RO_NCB + cb - j * (RO_KG / G)) & (RO_KG - 1);   // physical 16-column block of true block 8 wave + cb
+        *reinterpret_cast<ro_f4*>(tile0 + lrow * RO_LDA + pb * 16 + 4 * lq) = v;
+      }
+      w1_load(s + 1);   // (consumed a whole subnet later)
+      ro_barrier();
+    }
+    RC_PHASE(1)
+    // ---- hidden 2: tile0 (h1, complete) -> own columns of tile1 and X, epoch s + 1
+    RC_LAYER(2 * s, b2, tile0, rsX1, 0u, false)
+    RC_EPILOGUE(tile1, true, rsX1)
+    RC_PUBLISH(2 * e0 + 1)
+    RC_PHASE(2)
+    // ---- hidden 3: tile1 (h2) -> own columns of tile0 (h3 stays here)
+    RC_LAYER(2 * s + 1, b3, tile1, rsX1, 2 * e0 + 1, true)
+    RC_EPILOGUE(tile0, false, rsX1)
+    ro_barrier();
+    RC_PHASE(3)
+    // ---- last Linear over the member's own h3 columns: per-wave partial sums -> red[wave] -> the member's partial -> P[j], epoch 3 s + 3
+    {
+      ro_f4 p4[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) p4[cc] = ro_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const ro_f4 hf = *reinterpret_cast<const ro_f4*>(tile0 + lrow * RO_LDA + (wave * NCB + cb) * 16 + 4 * lq);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) p4[cc] = RO_MFMA(wl[cb][cc], hf[cc], p4[cc]);
+      }
+      const ro_f4 p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+      *reinterpret_cast<ro_f4*>(red + wave * (RO_ROWS * RO_RS) + lrow * RO_RS + 4 * lq) = p;
+      ro_barrier();
+      // the member's partial -> P[j] (write-through), epoch word, then every member sums the G partials in member order
+      float mine = 0.f;
+      if (t < 256) {
+        const int row = t >> 4, o = t & 15;
+#pragma unroll
+        for (int w = 0; w < RO_WAVES; ++w) mine += red[w * (RO_ROWS * RO_RS) + row * RO_RS + o];
+        __hip_atomic_store(P + j * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      RC_PUBLISH(2 * e0 + 2)
+      if (!wait_peers(2 * e0 + 2)) return;
+      if (t < 256) {
+        const int row = t >> 4, o = t & 15;
+        float part[G];
+#pragma unroll
+        for (int m = 0; m < G; ++m) part[m] = m == j ? mine : __hip_atomic_load(P + m * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float sum = sm[o];   // b_last (zero beyond n_out)
+#pragma unroll
+        for (int m = 0; m < G; ++m) sum += part[m];
+        s_sum[row * RO_RS + o] = sum;
+      }
+      ro_barrier();
+    }
+    RC_PHASE(4)
+    advance(sm, s + 1 < a.n_sub ? sm + RO_SMALL_WORDS : nullptr, xs + 256 * xcur, xs + 256 * (xcur ^ 1));
+    xcur ^= 1;
+    ro_barrier();
+    RC_PHASE(5)
+  }
+  RC_STAMP(33)
+  if (j == 0 && t < 256) {
+    const int row = t >> 4, jj = t & 15;
+    if (jj < a.ndof && m0 + row < a.M) {
+      const float* x = xs + 256 * xcur + row * 16;
+      float q = 0.f;
+      for (int k = 0; k < a.D; ++k) {
+        float xv = x[k];
+        if (a.sigmoid) xv = 1.0f / (1.0f + expf(-xv));
+        q = fmaf(xv - a.b_lin[k], a.M_inv[k * a.D + jj], q);
+      }
+      if (a.clamp_limits) q = fminf(fmaxf(q, a.lo[jj]), a.hi[jj]);
+      a.q_out[(size_t)(m0 + row) * a.ndof + jj] = q;
+    }
+  }
+  RC_STAMP(34)
+  if (a.trace != nullptr && t == 0) {
+    a.trace[(size_t)blockIdx.x * 64 + 36] = wall_clock64();
+    a.trace[(size_t)blockIdx.x * 64 + 35] = t0_wall;
+  }
+#undef RC_STAMP
+}
+
 // ---- the stream image of one subnet (see the header of this file); one thread per float4
 struct RoPackArgs {
   SubnetWeights w;
@@ -329,6 +680,30 @@ hipError_t launch_flow_rowowner(const RoArgs& a, int nbuf, hipStream_t s) {
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_flow_rowowner<4>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, a);
   }
+  return hipGetLastError();
+}
+
+size_t cluster_xbuf_floats(int n_rt) { return (size_t)n_rt * RO_ROWS * RO_W; }
+size_t cluster_sync_bytes(int n_rt, int G) { return (size_t)n_rt * G * (256 * 4 + 32 * 4) + 128; }   // partial sums, epoch words, abort word
+hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s) {
+  static bool done2[64] = {}, done4[64] = {}, done8[64] = {};
+  const unsigned grid = (unsigned)c.n_rt * (unsigned)G;
+  // epochs and granule tags count from 1 inside a call: everything polled is zeroed in front of it (one memset: pbuf and flags are one block)
+  hipError_t e = hipMemsetAsync(c.pbuf, 0, cluster_sync_bytes(c.n_rt, G), s);
+  if (e != hipSuccess) return e;
+  if (G == 2) {
+    e = ensure_dynamic_lds(k_flow_cluster<2>, RO_LDS_BYTES, done2);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_cluster<2>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  } else if (G == 4) {
+    e = ensure_dynamic_lds(k_flow_cluster<4>, RO_LDS_BYTES, done4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_cluster<4>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  } else if (G == 8) {
+    e = ensure_dynamic_lds(k_flow_cluster<8>, RO_LDS_BYTES, done8);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_cluster<8>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  } else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

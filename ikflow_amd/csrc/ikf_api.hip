@@ -99,6 +99,15 @@ struct ikf_model {
   int ro_mode = -1, ro_nbuf = 4;
   int n_cu = 256;
   long long ro_min_tail = -1;  // -1: 13/16 of a round
+  // Cluster form (k_flow_cluster<G>, flow_rowowner.hip) for what is left below a round: G = 8 / 4 / 2 workgroups per 16-row tile split the
+  // hidden columns and exchange activations inside the launch (<= 512 / 1024 / 2048 rows).  Every cluster launch is followed by a
+  // predicated row-owner launch of the same rows that runs only if a wait ran out (cl_abort set): results are valid either way, and the
+  // handle stops using the form (cl_give_up).   cl_mode: -1 by batch size, 0 never, 1 whenever the grid fits (ikf_set_gemm_variant 185 / 186 / 187)
+  int cl_mode = -1;
+  long long cl_rows = 0;          // row capacity of the exchange buffers
+  float* cl_xbuf = nullptr;       // [tiles][16][1024]
+  float* cl_sync = nullptr;       // partial sums, epoch words, abort word (one memset per launch)
+  int* h_cl_give_up = nullptr;    // pinned, device-visible
 
   // packed weights (one arena)
   float* arena = nullptr;
@@ -290,6 +299,8 @@ extern "C" ikf_status ikf_create(const ikf_model_desc* desc, int device, ikf_mod
   if (e == hipSuccess) e = hipMemset(m->d_arrive, 0, sizeof(unsigned) * kArriveWords);
   if (e == hipSuccess) e = hipHostMalloc(&m->h_give_up, sizeof(int), hipHostMallocMapped);
   if (e == hipSuccess) *m->h_give_up = 0;
+  if (e == hipSuccess) e = hipHostMalloc(&m->h_cl_give_up, sizeof(int), hipHostMallocMapped);
+  if (e == hipSuccess) *m->h_cl_give_up = 0;
   if (e == hipSuccess) e = hipMalloc(&m->d_chain_ctl, sizeof(unsigned) * IKF_CHAIN_CTL_WORDS);
   if (e == hipSuccess) e = hipMemset(m->d_chain_ctl, 0, sizeof(unsigned) * IKF_CHAIN_CTL_WORDS);
   if (e == hipSuccess) e = hipMalloc(&m->d_chain_tab, sizeof(ChainSubnet) * 2 * (size_t)desc->nb_nodes);
@@ -312,6 +323,9 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->wfrag_arena) (void)hipFree(m->wfrag_arena);
   if (m->ro_stream) (void)hipFree(m->ro_stream);
   if (m->d_ro_sub) (void)hipFree(m->d_ro_sub);
+  if (m->cl_xbuf) (void)hipFree(m->cl_xbuf);
+  if (m->cl_sync) (void)hipFree(m->cl_sync);
+  if (m->h_cl_give_up) (void)hipHostFree(m->h_cl_give_up);
   if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
   if (m->d_Minv) (void)hipFree(m->d_Minv);
   if (m->d_blin) (void)hipFree(m->d_blin);
@@ -703,6 +717,10 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->wt_stores = variant == 134 ? -1 : variant - 130;
     return IKF_OK;
   }
+  if (variant >= 185 && variant <= 187) {  // cluster form for the rows below a round: never / by batch size / whenever the grid fits
+    m->cl_mode = variant == 185 ? 0 : (variant == 186 ? -1 : 1);
+    return IKF_OK;
+  }
   if (variant >= 180 && variant <= 182) {  // row-owner form (one launch per call, rows resident on chip): never / by batch size / always
     if (variant == 182 && m->loaded && m->ro_stream == nullptr)
       return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_gemm_variant(182): the row-owner kernel needs coeff_fn_internal_size 1024 and coeff_fn_config 3");
@@ -1052,36 +1070,110 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
   return IKF_OK;
 }
 
-// rows [0, n_ro) of a batch go through the row-owner launch, the rest through the per-layer kernels
-static long long rowowner_rows(const ikf_model* m, long long rows) {
-  if (m->ro_stream == nullptr || m->ro_mode == 0 || m->precision != 0 || !m->loaded) return 0;
-  if (m->ro_mode == 1) return rows;
-  if (m->gemm_variant >= 0 || m->tile_cfg >= 0 || m->fuse_tail != 0) return 0;  // a forced per-layer form is being measured
+// ---- which form runs which rows of a batch -------------------------------------------------------------------------------------------
+// Three forms compute the same function: the per-layer kernels (any shape), the row-owner launch (a round of CUs x 16 rows costs the same
+// whatever part of it is used) and the cluster form (G = 8 / 4 / 2: <= 512 / 1024 / 2048 rows at a fixed cost each).  A batch is cut into
+// consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
+// tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
+//   row-owner round 2.82;  cluster 0.53 / 0.86 / 1.55;  per-layer 0.32 / 0.37 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to
+//   64 / 128 / 256 / 512 / 1024 / 2048 / 2560 / 3072 / 4096 rows;  + 0.01 per extra chunk (its launches' boundaries).
+// e.g. 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
+// 3400 -> one row-owner round; 4096 k + r -> k rounds in one row-owner launch + the plan of r.
+struct FlowChunk {
+  int form;         // 0 per-layer, 1 row-owner, 2 / 4 / 8 cluster members
+  long long rows;
+};
+static bool rowowner_allowed(const ikf_model* m) {
+  return m->ro_stream != nullptr && m->ro_mode != 0 && m->precision == 0 && m->loaded &&
+         (m->ro_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0));
+}
+static bool cluster_allowed(ikf_model* m) {
+  if (m->ro_stream == nullptr || m->cl_mode == 0 || m->precision != 0 || !m->loaded) return false;
+  if (m->h_cl_give_up && *m->h_cl_give_up != 0) {  // a wait of an earlier call ran out (its rows were recomputed by the repair launch):
+    m->cl_mode = 0;                                // the device is shared or partitioned - no more in-launch hand-overs on this handle
+    *m->h_cl_give_up = 0;
+    return false;
+  }
+  return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
+}
+static double per_layer_cost(long long rows_on_256) {
+  static const struct { long long rows; double ms; } t[] = {{64, 0.32}, {128, 0.37}, {256, 0.52}, {512, 0.71}, {1024, 1.04}, {2048, 1.75},
+                                                            {2560, 2.56}, {3072, 2.62}, {4096, 3.20}};
+  for (const auto& e : t)
+    if (rows_on_256 <= e.rows) return e.ms;
+  return 3.20 * (double)rows_on_256 / 4096.0;
+}
+// cheapest plan for `rows` rows below one row-owner round; returns its cost, appends its chunks
+static double plan_tail(long long rows, long long round, bool ro, bool cl, std::vector<FlowChunk>* out) {
+  if (rows <= 0) return 0.0;
+  const long long on256 = rows * 4096 / round;   // the cost tables are in rows of a 256-CU chip
+  double best = per_layer_cost(on256);
+  std::vector<FlowChunk> best_plan{{0, rows}};
+  if (ro && 2.82 < best) { best = 2.82; best_plan = {{1, rows}}; }
+  if (cl) {
+    static const struct { int G; double ms; } forms[] = {{8, 0.53}, {4, 0.86}, {2, 1.55}};
+    for (const auto& f : forms) {
+      const long long cap = round / f.G;   // rows of a full grid of this form
+      if (rows <= cap) {                   // the whole tail in one launch of this form
+        if (f.ms < best) { best = f.ms; best_plan = {{f.G, rows}}; }
+      } else {                             // a full launch of this form, then the plan of what is left
+        std::vector<FlowChunk> rest;
+        const double c = f.ms + 0.01 + plan_tail(rows - cap, round, ro, cl, &rest);
+        if (c < best) {
+          best = c;
+          best_plan = {{f.G, cap}};
+          best_plan.insert(best_plan.end(), rest.begin(), rest.end());
+        }
+      }
+    }
+  }
+  out->insert(out->end(), best_plan.begin(), best_plan.end());
+  return best;
+}
+static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
+  std::vector<FlowChunk> plan;
+  if (rows <= 0) return plan;
+  const bool ro = rowowner_allowed(m), cl = cluster_allowed(m);
   const long long round = (long long)m->n_cu * IKF_RO_ROWS;
-  const long long min_tail = m->ro_min_tail >= 0 ? m->ro_min_tail : round * 13 / 16;
-  const long long full = rows / round * round, rem = rows - full;
-  return full + (rem >= min_tail ? rem : 0);
+  if (ro && m->ro_mode == 1) return {{1, rows}};
+  if (cl && m->cl_mode == 1 && rows <= round / 2) {  // forced: one launch of the widest form whose grid fits
+    for (int g = 8; g >= 2; g /= 2)
+      if (rows <= round / g) return {{g, rows}};
+  }
+  const long long full = ro ? rows / round * round : 0;
+  std::vector<FlowChunk> tail;
+  if (rows - full > 0) {
+    if (ro && m->ro_min_tail >= 0) {  // (probes: an explicit threshold for the last partial round)
+      if (rows - full >= m->ro_min_tail) tail = {{1, rows - full}};
+      else tail = {{0, rows - full}};
+    } else plan_tail(rows - full, round, ro, cl, &tail);
+  }
+  if (full > 0) plan.push_back({1, full});
+  for (const FlowChunk& c : tail) {
+    if (!plan.empty() && plan.back().form == 1 && c.form == 1) plan.back().rows += c.rows;   // the partial round rides in the same launch
+    else plan.push_back(c);
+  }
+  return plan;
 }
-extern "C" const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows) {
-  if (m && rows > 0 && 2 * rowowner_rows(m, rows) >= rows) return rowowner_kernel_name();
-  return (m && m->precision == 1 && m->split_arena) ? split_kernel_name() : fused_kernel_name();
-}
-static ikf_status run_flow_rowowner(ikf_model* m, const PoseSource& ps, const float* d_latent, long long rows, int clamp_limits,
-                                    float* d_q_out, hipStream_t s) {
+static RoArgs rowowner_args(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r0, long long nr, int clamp_limits, float* d_q_out) {
   const FlowDims& d = m->dims;
+  RoArgs a{};
+  a.stream = m->ro_stream;
+  a.stream_bytes = (unsigned)(rowowner_stream_floats(2 * m->desc.nb_nodes) * sizeof(float));
+  a.sub = m->d_ro_sub; a.n_sub = 2 * m->desc.nb_nodes;
+  a.x0 = d_latent + (size_t)r0 * d.D;
+  a.ps = ps; a.row0 = r0; a.M = (int)nr; a.D = d.D; a.L1 = d.L1; a.ndof = d.ndof; a.clamp = d.clamp; a.slope = d.slope;
+  a.M_inv = m->d_Minv; a.b_lin = m->d_blin; a.lo = chain_lo(m); a.hi = chain_hi(m);
+  a.clamp_limits = clamp_limits; a.sigmoid = m->desc.sigmoid_on_output ? 1 : 0;
+  a.q_out = d_q_out + (size_t)r0 * d.ndof;
+  return a;
+}
+static ikf_status run_flow_rowowner(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r_base, long long rows,
+                                    int clamp_limits, float* d_q_out, hipStream_t s) {
   const long long kMaxLaunchRows = 1LL << 24;
-  for (long long r0 = 0; r0 < rows; r0 += kMaxLaunchRows) {
-    const long long nr = rows - r0 < kMaxLaunchRows ? rows - r0 : kMaxLaunchRows;
-    RoArgs a{};
-    a.stream = m->ro_stream;
-    a.stream_bytes = (unsigned)(rowowner_stream_floats(2 * m->desc.nb_nodes) * sizeof(float));
-    a.sub = m->d_ro_sub; a.n_sub = 2 * m->desc.nb_nodes;
-    a.x0 = d_latent + (size_t)r0 * d.D;
-    a.ps = ps; a.row0 = r0; a.M = (int)nr; a.D = d.D; a.L1 = d.L1; a.ndof = d.ndof; a.clamp = d.clamp; a.slope = d.slope;
-    a.M_inv = m->d_Minv; a.b_lin = m->d_blin; a.lo = chain_lo(m); a.hi = chain_hi(m);
-    a.clamp_limits = clamp_limits; a.sigmoid = m->desc.sigmoid_on_output ? 1 : 0;
-    a.q_out = d_q_out + (size_t)r0 * d.ndof;
-    a.trace = nullptr;
+  for (long long r0 = r_base; r0 < r_base + rows; r0 += kMaxLaunchRows) {
+    const long long nr = r_base + rows - r0 < kMaxLaunchRows ? r_base + rows - r0 : kMaxLaunchRows;
+    const RoArgs a = rowowner_args(m, ps, d_latent, r0, nr, clamp_limits, d_q_out);
     IKF_HIP(prof_mark(m, s));
     IKF_HIP(launch_flow_rowowner(a, m->ro_nbuf, s));
     IKF_HIP(prof_mark(m, s));
@@ -1089,22 +1181,68 @@ static ikf_status run_flow_rowowner(ikf_model* m, const PoseSource& ps, const fl
   return IKF_OK;
 }
 
+static ikf_status ensure_cluster_scratch(ikf_model* m, long long rows) {
+  if (rows <= m->cl_rows) return IKF_OK;
+  if (m->cl_xbuf) (void)hipFree(m->cl_xbuf);
+  if (m->cl_sync) (void)hipFree(m->cl_sync);
+  m->cl_xbuf = nullptr; m->cl_sync = nullptr; m->cl_rows = 0;
+  const long long cap = (long long)m->n_cu / 2 * IKF_RO_ROWS;   // the largest chunk the form takes (G = 2)
+  const int tiles = (int)((cap + IKF_RO_ROWS - 1) / IKF_RO_ROWS);
+  IKF_HIP(hipMalloc(&m->cl_xbuf, sizeof(float) * cluster_xbuf_floats(tiles)));
+  IKF_HIP(hipMalloc(&m->cl_sync, cluster_sync_bytes(tiles, 8)));   // (sized for G = 8 on every tile: 4.6 KB per tile)
+  m->cl_rows = cap;
+  return IKF_OK;
+}
+static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, const float* d_latent, long long r0, long long nr,
+                                   int clamp_limits, float* d_q_out, hipStream_t s) {
+  ikf_status st = ensure_cluster_scratch(m, nr);
+  if (st != IKF_OK) return st;
+  RcArgs c{};
+  c.ro = rowowner_args(m, ps, d_latent, r0, nr, clamp_limits, d_q_out);
+  c.n_rt = (int)((nr + IKF_RO_ROWS - 1) / IKF_RO_ROWS);
+  c.xbuf = m->cl_xbuf;
+  c.pbuf = m->cl_sync;
+  c.flags = reinterpret_cast<unsigned*>(m->cl_sync) + (size_t)c.n_rt * G * 256;
+  c.abort_word = c.flags + (size_t)c.n_rt * G * 32;
+  c.give_up = m->h_cl_give_up;
+  IKF_HIP(prof_mark(m, s));
+  IKF_HIP(launch_flow_cluster(c, G, s));
+  IKF_HIP(prof_mark(m, s));
+  // the repair launch: the same rows through the row-owner kernel, which returns at once unless a wait of the cluster launch ran out
+  RoArgs rep = c.ro;
+  rep.run_if = c.abort_word;
+  IKF_HIP(launch_flow_rowowner(rep, m->ro_nbuf, s));
+  return IKF_OK;
+}
+
+extern "C" const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows) {
+  if (m && rows > 0) {
+    long long by_form[3] = {0, 0, 0};
+    for (const FlowChunk& c : plan_flow(const_cast<ikf_model*>(m), rows)) by_form[c.form >= 2 ? 2 : c.form] += c.rows;
+    if (by_form[1] >= by_form[0] && by_form[1] >= by_form[2] && by_form[1] > 0) return rowowner_kernel_name();
+    if (by_form[2] >= by_form[0] && by_form[2] > 0) return "k_flow_cluster";
+  }
+  return (m && m->precision == 1 && m->split_arena) ? split_kernel_name() : fused_kernel_name();
+}
 static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
                            float* d_q_out, hipStream_t s) {
-  const long long n_ro = rowowner_rows(m, rows);
-  ikf_status st = IKF_OK;
-  if (n_ro > 0) {
-    st = run_flow_rowowner(m, ps, d_latent, n_ro, clamp_limits, d_q_out, s);
-    if (st != IKF_OK || n_ro == rows) return st;
-  }
-  st = ensure_scratch(m, rows - n_ro);
-  if (st != IKF_OK) return st;
+  const std::vector<FlowChunk> plan = plan_flow(m, rows);
   const bool fused = fused_ok(m);
-  for (long long r0 = n_ro; r0 < rows; r0 += m->chunk_rows) {
-    const long long nr = (rows - r0 < m->chunk_rows) ? rows - r0 : m->chunk_rows;
-    st = fused ? run_flow_chunk_fused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s)
-               : run_flow_chunk_unfused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s);
+  long long r_base = 0;
+  for (const FlowChunk& c : plan) {
+    ikf_status st = IKF_OK;
+    if (c.form == 1) st = run_flow_rowowner(m, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
+    else if (c.form >= 2) st = run_flow_cluster(m, c.form, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
+    else {
+      st = ensure_scratch(m, c.rows);
+      for (long long r0 = r_base; st == IKF_OK && r0 < r_base + c.rows; r0 += m->chunk_rows) {
+        const long long nr = (r_base + c.rows - r0 < m->chunk_rows) ? r_base + c.rows - r0 : m->chunk_rows;
+        st = fused ? run_flow_chunk_fused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s)
+                   : run_flow_chunk_unfused(m, ps, d_latent, r0, nr, clamp_limits, d_q_out, s);
+      }
+    }
     if (st != IKF_OK) return st;
+    r_base += c.rows;
   }
   return IKF_OK;
 }

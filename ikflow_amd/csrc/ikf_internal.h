@@ -226,8 +226,22 @@ struct RoArgs {
   int clamp_limits, sigmoid;
   float* q_out;            // [M][ndof]
   unsigned long long* trace;   // probes: [grid][64] shader-clock stamps, or null
+  const unsigned* run_if;  // null, or a device word: the launch does nothing unless it is non-zero (the cluster form's repair launch)
 };
 
+struct RcArgs {            // cluster form (k_flow_cluster<G>): G workgroups per row tile split the hidden columns
+  RoArgs ro;
+  int n_rt;                // row tiles = ceil(M / 16); grid = n_rt * G workgroups, all resident
+  float* xbuf;             // [n_rt][16][1024] exchanged h2 tiles
+  float* pbuf;             // [n_rt][G][16][16] last-Linear partial sums per member
+  unsigned* flags;         // [n_rt][G][32] epoch published by each member (one 128-byte line each) = pbuf + n_rt * G * 256 (one memset)
+  unsigned* abort_word;    // device word behind the flags (same memset): set when a wait ran out - every other wait ends, and the
+                           // row-owner launch queued behind this one (run_if = abort_word) recomputes the chunk
+  int* give_up;            // host-visible twin: the engine stops using the cluster form on this handle
+};
+size_t cluster_xbuf_floats(int n_rt);
+size_t cluster_sync_bytes(int n_rt, int G);   // pbuf + flags + the abort word
+hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s);
 constexpr int IKF_RO_ROWS = 16;                       // rows per workgroup
 size_t rowowner_subnet_floats();                        // floats of one subnet's stream image
 size_t rowowner_stream_floats(int n_sub);               // whole image incl. the ring's lead padding

@@ -1,4 +1,4 @@
-"""Row-owner launch (ikf_set_gemm_variant 182) against the per-layer kernels (180) and the default split (181) by batch size.
+"""Row-owner launch (ikf_set_gemm_variant 182) and cluster form (187) against the per-layer kernels (180 + 185) and the default split by batch size.
 usage: PYTHONPATH=. python tools/rowowner_ab.py [rows,rows,...] [out.jsonl]
 Prints ms per call for each form - where the last partial round of a batch should switch from the per-layer kernels to the row-owner launch."""
 import json
@@ -27,8 +27,13 @@ for rows in rows_list:
     p = robot.forward_kinematics(q)
     l = torch.randn(rows, layout.dim, generator=torch.Generator().manual_seed(1)).to(dev)
     rec = {"rows": rows}
-    for name, variant in (("per_layer", 180), ("row_owner", 182), ("default", 181)):
-        eng.set_gemm_variant(variant)
+    for name, variants in (("per_layer", (180, 185)), ("row_owner", (182, 185)), ("cluster", (180, 187)), ("default", (181, 186))):
+        if name == "cluster" and rows > 2048:
+            continue
+        if name == "row_owner" and rows < 2048:
+            continue
+        for variant in variants:
+            eng.set_gemm_variant(variant)
         reps = max(5, min(50, int(200e3 / rows)))
         for _ in range(3):
             solver.generate_ik_solutions(p, latent=l)
@@ -39,6 +44,7 @@ for rows in rows_list:
         torch.cuda.synchronize(dev)
         rec[name + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
     eng.set_gemm_variant(181)
+    eng.set_gemm_variant(186)
     rec["default_Msol_per_s"] = round(rows / rec["default_ms"] * 1e-3, 4)
     print(json.dumps(rec), flush=True)
     if out:

@@ -3,7 +3,9 @@
 // host reference of the inverse pass; prints ms per call, shader cycles per subnet (median over the workgroups) against the
 // 2 x 131,072-cycle matrix-pipe floor, and the spread over workgroups.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/rowowner_probe.hip -o tools/bin/rowowner_probe
-//   tools/bin/rowowner_probe [rows=4096] [iters=20] [nbuf=4] [blocks=12] [D=7]
+//   tools/bin/rowowner_probe [rows=4096] [iters=20] [nbuf=4] [blocks=12] [D=7] [G=1]
+// G = 2 / 4 / 8: the cluster form (k_flow_cluster<G>: G workgroups per 16-row tile split the hidden columns and exchange activations
+// through global memory) - rows * G / 16 must not exceed the CU count.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -27,6 +29,7 @@ int main(int argc, char** argv) {
   const int nbuf = argc > 3 ? atoi(argv[3]) : 4;
   const int NB = argc > 4 ? atoi(argv[4]) : 12;
   const int D = argc > 5 ? atoi(argv[5]) : 7;
+  const int G = argc > 6 ? atoi(argv[6]) : 1;
   const int L1 = D / 2, L2 = D - L1, W = RO_W, ndof = 7;
   const int n_sub = 2 * NB;
   std::mt19937 rng(7);
@@ -94,14 +97,31 @@ int main(int argc, char** argv) {
   for (int k = 0; k < D; ++k) Minv[(size_t)k * D + k] = k < ndof ? 2.9f : 1.f;
   float *d_x = up(hx), *d_p = up(hp), *d_Minv = up(Minv), *d_blin = up(blin), *d_lo = up(lo), *d_hi = up(hi), *d_q;
   CK(hipMalloc(&d_q, (size_t)M * ndof * 4));
-  const unsigned grid = (M + RO_ROWS - 1) / RO_ROWS;
+  const unsigned grid = (M + RO_ROWS - 1) / RO_ROWS * (argc > 6 ? atoi(argv[6]) : 1);
   unsigned long long* d_trace; CK(hipMalloc(&d_trace, (size_t)grid * 64 * 8)); CK(hipMemset(d_trace, 0, (size_t)grid * 64 * 8));
   RoArgs a{};
   a.stream = d_stream; a.stream_bytes = (unsigned)(stream_floats * 4); a.sub = d_sub; a.n_sub = n_sub; a.x0 = d_x;
   a.ps = PoseSource{d_p, nullptr, (long long)M, 7, 0.f}; a.row0 = 0; a.M = M; a.D = D; a.L1 = L1; a.ndof = ndof; a.clamp = 2.5f; a.slope = 0.01f;
   a.M_inv = d_Minv; a.b_lin = d_blin; a.lo = d_lo; a.hi = d_hi; a.clamp_limits = 1; a.sigmoid = 0; a.q_out = d_q; a.trace = nullptr;
+  RcArgs rc{};
+  int* h_give_up = nullptr;
+  if (G > 1) {
+    rc.n_rt = (M + RO_ROWS - 1) / RO_ROWS;
+    CK(hipMalloc(&rc.xbuf, cluster_xbuf_floats(rc.n_rt) * 4));
+    CK(hipMalloc(&rc.pbuf, cluster_sync_bytes(rc.n_rt, G)));
+    rc.flags = reinterpret_cast<unsigned*>(rc.pbuf + (size_t)rc.n_rt * G * 256);
+    rc.abort_word = rc.flags + (size_t)rc.n_rt * G * 32;
+    CK(hipHostMalloc(&h_give_up, 4, hipHostMallocMapped)); *h_give_up = 0;
+    rc.give_up = h_give_up;
+  }
+  auto launch = [&]() -> hipError_t {
+    if (G > 1) { rc.ro = a; return launch_flow_cluster(rc, G, nullptr); }
+    return launch_flow_rowowner(a, nbuf, nullptr);
+  };
+#define launch_flow_rowowner(a_, n_, s_) launch()
   CK(launch_flow_rowowner(a, nbuf, nullptr));
   CK(hipDeviceSynchronize());
+  if (h_give_up && *h_give_up) { printf("GIVE UP: a wait ran out\n"); return 3; }
   std::vector<float> hq((size_t)M * ndof);
   CK(hipMemcpy(hq.data(), d_q, hq.size() * 4, hipMemcpyDeviceToHost));
   // fp64 reference on the first and the last 16 rows
@@ -154,7 +174,7 @@ int main(int argc, char** argv) {
       max_err = std::max(max_err, fabs(q - (double)hq[(size_t)r * ndof + j]));
     }
   }
-  printf("rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
+  printf("G %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
   // timing
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) CK(launch_flow_rowowner(a, nbuf, nullptr));
