@@ -120,6 +120,7 @@ SIGNATURES = {
     "ikf_split_kernel_name": (C.c_char_p, []),
     "ikf_dominant_kernel_name": (C.c_char_p, []),
     "ikf_dominant_kernel_for": (C.c_char_p, [C.c_void_p, C.c_int64]),
+    "ikf_cluster_repairs": (C.c_int64, [C.c_void_p]),
     "ikf_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
 }
 

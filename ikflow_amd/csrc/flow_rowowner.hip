@@ -685,9 +685,10 @@ hipError_t launch_flow_rowowner(const RoArgs& a, int nbuf, hipStream_t s) {
 
 size_t cluster_xbuf_floats(int n_rt) { return (size_t)n_rt * RO_ROWS * RO_W; }
 size_t cluster_sync_bytes(int n_rt, int G) { return (size_t)n_rt * G * (256 * 4 + 32 * 4) + 128; }   // partial sums, epoch words, abort word
-hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s) {
+hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups) {
   static bool done2[64] = {}, done4[64] = {}, done8[64] = {};
-  const unsigned grid = (unsigned)c.n_rt * (unsigned)G;
+  // (drop_workgroups > 0: tests of the repair path - the last workgroups are not launched, their row tile's members wait in vain)
+  const unsigned grid = (unsigned)c.n_rt * (unsigned)G - (unsigned)(drop_workgroups > 0 ? 1 : 0);
   // epochs and granule tags count from 1 inside a call: everything polled is zeroed in front of it (one memset: pbuf and flags are one block)
   hipError_t e = hipMemsetAsync(c.pbuf, 0, cluster_sync_bytes(c.n_rt, G), s);
   if (e != hipSuccess) return e;

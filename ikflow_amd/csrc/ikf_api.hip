@@ -108,6 +108,8 @@ struct ikf_model {
   float* cl_xbuf = nullptr;       // [tiles][16][1024]
   float* cl_sync = nullptr;       // partial sums, epoch words, abort word (one memset per launch)
   int* h_cl_give_up = nullptr;    // pinned, device-visible
+  int cl_drop_next = 0;           // tests: the next cluster launch runs one workgroup short (ikf_set_gemm_variant 188): its tile's waits run out
+  long long cl_repairs = 0;       // give-ups seen so far (ikf_cluster_repairs)
 
   // packed weights (one arena)
   float* arena = nullptr;
@@ -717,6 +719,10 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->wt_stores = variant == 134 ? -1 : variant - 130;
     return IKF_OK;
   }
+  if (variant == 188) {  // tests of the repair path: the next cluster launch is one workgroup short
+    m->cl_drop_next = 1;
+    return IKF_OK;
+  }
   if (variant >= 185 && variant <= 187) {  // cluster form for the rows below a round: never / by batch size / whenever the grid fits
     m->cl_mode = variant == 185 ? 0 : (variant == 186 ? -1 : 1);
     return IKF_OK;
@@ -1092,6 +1098,7 @@ static bool cluster_allowed(ikf_model* m) {
   if (m->h_cl_give_up && *m->h_cl_give_up != 0) {  // a wait of an earlier call ran out (its rows were recomputed by the repair launch):
     m->cl_mode = 0;                                // the device is shared or partitioned - no more in-launch hand-overs on this handle
     *m->h_cl_give_up = 0;
+    ++m->cl_repairs;
     return false;
   }
   return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
@@ -1206,7 +1213,8 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
   c.abort_word = c.flags + (size_t)c.n_rt * G * 32;
   c.give_up = m->h_cl_give_up;
   IKF_HIP(prof_mark(m, s));
-  IKF_HIP(launch_flow_cluster(c, G, s));
+  IKF_HIP(launch_flow_cluster(c, G, s, m->cl_drop_next));
+  m->cl_drop_next = 0;
   IKF_HIP(prof_mark(m, s));
   // the repair launch: the same rows through the row-owner kernel, which returns at once unless a wait of the cluster launch ran out
   RoArgs rep = c.ro;
@@ -1215,6 +1223,11 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
   return IKF_OK;
 }
 
+extern "C" int64_t ikf_cluster_repairs(ikf_model* m) {
+  if (!m) return 0;
+  (void)cluster_allowed(m);  // (folds a pending give-up word in)
+  return (int64_t)m->cl_repairs;
+}
 extern "C" const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows) {
   if (m && rows > 0) {
     long long by_form[3] = {0, 0, 0};

@@ -241,7 +241,7 @@ struct RcArgs {            // cluster form (k_flow_cluster<G>): G workgroups per
 };
 size_t cluster_xbuf_floats(int n_rt);
 size_t cluster_sync_bytes(int n_rt, int G);   // pbuf + flags + the abort word
-hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s);
+hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups = 0);
 constexpr int IKF_RO_ROWS = 16;                       // rows per workgroup
 size_t rowowner_subnet_floats();                        // floats of one subnet's stream image
 size_t rowowner_stream_floats(int n_sub);               // whole image incl. the ring's lead padding

@@ -403,6 +403,11 @@ class Engine:
         self.last_event_overhead_ms = float(self.lib.ikf_profile_event_overhead_ms(self._h))
         return int(n.value), float(ms.value)
 
+    @property
+    def cluster_repairs(self) -> int:
+        """Calls whose cluster-form launch gave up waiting for a peer workgroup (recomputed by the repair launch; form then disabled)."""
+        return int(self.lib.ikf_cluster_repairs(self._h))
+
     def dominant_kernel_name(self, rows: Optional[int] = None) -> str:
         """Name (as in a rocprofv3 kernel trace) of the kernel that carries a batch of `rows` rows; None: the per-layer contraction."""
         if rows is not None:

@@ -247,6 +247,10 @@ const char* ikf_dominant_kernel_name(void);
 /* ... of the kernel that carries (most of) a batch of `rows` rows on this handle with its current settings: "k_flow_rowowner" for
  * batches that take the one-launch row-owner form, else the per-layer contraction of the selected precision. */
 const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
+/* Cluster form (workgroups of one launch exchange activations): number of calls in which a wait ran out - a peer workgroup was not
+ * resident, i.e. the device is shared or partitioned.  Such a call's rows were recomputed by the row-owner launch queued behind it (the
+ * caller's results are valid), and the handle stopped using the form.  Meaningful once the stream of those calls has been synchronised. */
+int64_t ikf_cluster_repairs(ikf_model* m);
 /* Select the flow pipeline (a tuning / test switch; every setting computes the same function):
  *   -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly, 101..108 the fused form with tile
  *   configuration 0..7 forced, 160 with the 16 x 32 small-batch tiles forced; 0..8 the unfused 4-kernel form with that tile variant;
@@ -258,6 +262,9 @@ const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
  *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced
  *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced
  *   170 / 171        <= 128 rows: the whole subnet chain in one launch, hand-over between layers inside each XCD: off (default) / on
+ *   185 / 186 / 187  cluster form for 257 .. 3327 rows (G = 8 / 4 / 2 workgroups per 16-row tile split the hidden columns and exchange
+ *                    activations inside the launch): never / by the cost model (default) / whenever its grid fits; 188: tests - the next
+ *                    cluster launch runs one workgroup short (exercises the repair launch)
  *   180 / 181 / 182  row-owner form (ONE launch per call; a workgroup keeps 16 rows on chip through every subnet, weights streamed
  *                    past them; width 1024, coeff_fn_config 3): never / by batch size (default: full rounds of CUs x 16 rows and a
  *                    last partial round of >= 13/16 of one) / always

@@ -1493,6 +1493,32 @@ def test_cluster_form_default_split_and_many_calls_in_flight():
     assert (first[512].cpu() - ref).abs().max().item() <= FLOW_TOL
 
 
+def test_cluster_form_repair_launch_when_a_peer_never_arrives():
+    """A cluster launch one workgroup short (ikf_set_gemm_variant 188): the members of that workgroup's row tile wait in vain, the wait
+    runs out (bounded), every other wait ends through the abort word, and the predicated row-owner launch queued behind it recomputes the
+    rows - the caller's results are the row-owner form's, bit for bit, with no error; the handle counts the repair and stops using the form."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 512
+    _, poses = reachable_poses(robot, n, 27)
+    lat = latents(n, lay.dim, 28)
+    P, L = poses.to(DEV), lat.to(DEV)
+    eng.set_gemm_variant(182)
+    ro = s.generate_ik_solutions(P, latent=L)
+    eng.set_gemm_variant(181)
+    good = s.generate_ik_solutions(P, latent=L)
+    assert "cluster" in eng.dominant_kernel_name(n) and eng.cluster_repairs == 0
+    eng.set_gemm_variant(188)
+    out = torch.full_like(good, float("nan"))
+    out.copy_(s.generate_ik_solutions(P, latent=L))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ro), "the repair launch's rows"
+    assert eng.cluster_repairs == 1 and "cluster" not in eng.dominant_kernel_name(n)
+    again = s.generate_ik_solutions(P, latent=L)   # per-layer kernels from now on
+    assert (again - good).abs().max().item() <= FLOW_TOL and eng.cluster_repairs == 1
+
+
 def test_row_owner_form_is_what_the_baseline_batch_runs():
     """By default a batch's full rounds of (CUs x 16) rows and a last partial round of >= 13/16 of one take the row-owner launch, the
     rest the per-layer kernels: 4096 rows = one launch, 4096 + 200 = one launch + a 200-row per-layer chunk; results are those of the
