@@ -108,8 +108,7 @@ int main(int argc, char** argv) {
     return 4;
   }
   std::printf("cabi_demo: exact IK %lld / %lld poses solved (flow rows %lld)\n", (long long)n_valid, (long long)n, (long long)stats[1]);
-  std::printf("cabi_demo: %lld solutions, q[0] = %.6f %.6f %.6f ..., abi %d, kernel %s\n", (long long)n, q[0], q[1], q[2],
-              ikf_abi_version(), ikf_dominant_kernel_name());
+  std::printf("cabi_demo: %lld solutions, q[0] = %.6f %.6f %.6f ..., abi %d\n", (long long)n, q[0], q[1], q[2], ikf_abi_version());
   ikf_destroy(m);
   return 0;
 }

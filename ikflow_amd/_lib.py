@@ -121,21 +121,24 @@ SIGNATURES = {
     "ikf_dominant_kernel_name": (C.c_char_p, []),
     "ikf_dominant_kernel_for": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "ikf_cluster_repairs": (C.c_int64, [C.c_void_p]),
+    "ikf_probes_build": (C.c_int, []),
     "ikf_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 LIB_PATH = _build.LIB_PATH
-_lib = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """dlopen the in-tree library and bind every declared symbol. Raises if anything is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def load(flavour: str = "") -> C.CDLL:
+    """dlopen the in-tree library and bind every declared symbol. Raises if anything is missing.
+    flavour "probes": lib/libikflow_amd_probes.so (-DIKF_PROBES: the product plus the priced-and-rejected forms of rounds 2 - 3; tests and
+    tools only - both flavours may be loaded in one process, each handle belongs to the library that created it)."""
+    if flavour in _libs:
+        return _libs[flavour]
+    LIB_PATH = _build.lib_path(flavour)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP engine has not been built (run `python -m ikflow_amd.build`). "
+            f"{LIB_PATH} is missing: the HIP engine has not been built (run `python -m ikflow_amd.build{' --probes' if flavour else ''}`). "
             "ikflow_amd has no CPU path."
         )
     # torch FIRST: it ships its own copy of the HIP runtime (torch/lib/libamdhip64.so); if this library were loaded before
@@ -152,9 +155,11 @@ def load() -> C.CDLL:
     got = lib.ikf_abi_version()
     if got != IKF_ABI_VERSION:
         raise ImportError(f"libikflow_amd.so ABI {got} != binding ABI {IKF_ABI_VERSION}; rebuild the library")
-    _lib = lib
+    if bool(lib.ikf_probes_build()) != (flavour == "probes"):
+        raise ImportError(f"{LIB_PATH} is not the {'probes' if flavour else 'product'} flavour; rebuild it")
+    _libs[flavour] = lib
     return lib
 
 
-def last_error() -> str:
-    return load().ikf_last_error().decode("utf-8", "replace")
+def last_error(lib: C.CDLL = None) -> str:
+    return (lib or load()).ikf_last_error().decode("utf-8", "replace")

@@ -1779,6 +1779,7 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
 //     33rd ticket, or a wait that runs out (~1 s), sets the host-visible give-up word and the abort word that ends every other wait.
 //   * The last workgroup to leave zeroes the control words for the next call.
 // ---------------------------------------------------------------------------------------------------------------
+#ifdef IKF_PROBES
 __device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
 
 struct XcdWait {
@@ -1862,6 +1863,7 @@ __global__ __launch_bounds__(KKS * 64) void k_flow_chain16(const ChainSubnet* __
 // fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
 //   (((tn32*KT + kt)*KKS + kq)*KKG + kk)*64 + lane  <-  W[tn32*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
 // (per 32-column tile and k tile: 8 k-slices x 2 MFMA groups x 64 lanes; a wave's fetch for one stage is 2 KB contiguous)
+#endif  // IKF_PROBES
 __global__ __launch_bounds__(256) void k_wfrag_pack(const float* __restrict__ W, float* __restrict__ out, int N, int K) {
   const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= (size_t)N * K / 4) return;
@@ -1900,6 +1902,7 @@ static hipError_t launch_skinny(const FusedGemmArgs& a, hipStream_t s) {
   if (NH == 2 || tiles > 256) return launch_skinny_t<EPI_RED, NH, true>(a, s);
   return launch_skinny_t<EPI_RED, NH, false>(a, s);
 }
+#ifdef IKF_PROBES
 static hipError_t launch_skinny_tail(const FusedGemmArgs& a, const FuseTail& ft, hipStream_t s) {
   constexpr int NH = 2;
   constexpr size_t smem = skinny_lds<NH>();
@@ -1910,6 +1913,7 @@ static hipError_t launch_skinny_tail(const FusedGemmArgs& a, const FuseTail& ft,
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NH * KKS * 64), smem, s, a, ft);
   return hipGetLastError();
 }
+#endif  // IKF_PROBES
 
 template <bool EPI_RED, int NH>
 static hipError_t launch_entry_gemm_t(const EntryArgs& e, const FusedGemmArgs& a, int n_in, hipStream_t s) {
@@ -1946,6 +1950,14 @@ static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a
   return hipGetLastError();
 }
 
+// ---- the priced alternatives of rounds 2 - 3 ("measurement log") are compiled only into the probes library
+// (-DIKF_PROBES, ikflow_amd/lib/libikflow_amd_probes.so): the one-launch subnet chain for <= 128 rows (k_flow_chain16), the next subnet's
+// entry phase in the tail of a contraction (TailSync), tile configurations 5 / 7 / 11.  The shipped library answers "not supported".
+#ifndef IKF_PROBES
+bool flow_chain16_ok(long long, int, int, int, int) { return false; }
+hipError_t launch_xcd_census(unsigned*, hipStream_t) { return hipErrorNotSupported; }
+hipError_t launch_flow_chain16(const ChainSubnet*, int, const ChainCall&, const ChainSync&, int, hipStream_t) { return hipErrorNotSupported; }
+#else
 constexpr size_t kChainLds = 84 * 1024;  // more than half a CU's LDS: one chain workgroup per CU
 bool flow_chain16_ok(long long rows, int width, int D, int n_out, int n_hidden) {
   return rows >= 1 && rows <= (long long)S16_ROWS * IKF_CHAIN_XCDS && n_hidden == 3 && width == 32 * IKF_CHAIN_PER_XCD &&
@@ -1974,6 +1986,7 @@ hipError_t launch_flow_chain16(const ChainSubnet* d_tab, int n_sub, const ChainC
   }
   return hipGetLastError();
 }
+#endif  // IKF_PROBES
 
 // true when the first hidden contraction of a subnet can run as k_entry_gemm_skinny for this batch
 bool entry_gemm_ok(int cfg, long long rows, int width, int D, int n_out) {
@@ -2006,9 +2019,13 @@ hipError_t launch_entry_gemm(int n_in, bool epi_red, int cfg, const EntryArgs& e
     return epi_red ? launch_entry_gemm16<true, false, 1>(e, a, n_in, s) : launch_entry_gemm16<false, false, 1>(e, a, n_in, s);
   }
   if (cfg == 11) {
+#ifdef IKF_PROBES
     if ((a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK)
       return epi_red ? launch_entry_gemm16<true, true, 2, 2>(e, a, n_in, s) : launch_entry_gemm16<false, true, 2, 2>(e, a, n_in, s);
     return epi_red ? launch_entry_gemm16<true, false, 2, 2>(e, a, n_in, s) : launch_entry_gemm16<false, false, 2, 2>(e, a, n_in, s);
+#else
+    return hipErrorNotSupported;
+#endif
   }
   if (cfg == 4) return epi_red ? launch_entry_gemm_t<true, 2>(e, a, n_in, s) : launch_entry_gemm_t<false, 2>(e, a, n_in, s);
   return epi_red ? launch_entry_gemm_t<true, 1>(e, a, n_in, s) : launch_entry_gemm_t<false, 1>(e, a, n_in, s);
@@ -2074,6 +2091,7 @@ static hipError_t launch_fg(const FusedGemmArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a, NoTail{});
   return hipGetLastError();
 }
+#ifdef IKF_PROBES
 static hipError_t launch_fg_tail(const FusedGemmArgs& a, const FuseTail& ft, hipStream_t s) {
   using TC = TileCfg<0>;
   constexpr int NT = TC::WAVES_M * TC::WAVES_N * 64;
@@ -2085,12 +2103,16 @@ static hipError_t launch_fg_tail(const FusedGemmArgs& a, const FuseTail& ft, hip
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, s, a, ft);
   return hipGetLastError();
 }
+#endif  // IKF_PROBES
 
 // The in-launch hand-over needs every workgroup of the launch resident at once (a workgroup waits for its row tile's other
 // column tiles): both kernels that carry it run one workgroup per CU (LDS), so the grid may have at most 256 tiles.
 constexpr int kResidentTiles = 256;
 int fused_tail_col_tiles(int cfg, int width) { return cfg == 0 ? width / TileCfg<0>::BN : width / KBN; }
 bool fused_tail_ok(int cfg, long long rows, int width, int D, int n_out) {
+#ifndef IKF_PROBES
+  return false;
+#endif
   if (cfg != 0 && cfg != kSkinnyCfg) return false;
   const int bm = cfg == 0 ? TileCfg<0>::BM : KBM, bn = cfg == 0 ? TileCfg<0>::BN : KBN;
   if (width % bn != 0 || width / 64 > 32) return false;  // (the sc1 slot loads cover the first 32 slots)
@@ -2103,21 +2125,31 @@ hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArg
   if (!fused_tail_ok(cfg, a.M, a.N, e.D, e.pend.n_out) || a.K != a.N || a.n_out > 16 || ts.n_in > ROWBUF - 1 || e.width != a.N ||
       e.split_out || ts.arrive == nullptr || ts.give_up == nullptr || (cfg == kSkinnyCfg && a.Wf == nullptr) || a.K % 64 != 0 || a.K < 128)
     return hipErrorInvalidValue;
+#ifdef IKF_PROBES
   FuseTail ft{e, ts};
   return cfg == 0 ? launch_fg_tail(a, ft, s) : launch_skinny_tail(a, ft, s);
+#else
+  return hipErrorNotSupported;
+#endif
 }
 
 hipError_t launch_flow_gemm(bool epi_red, int cfg, const FusedGemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
+#ifdef IKF_PROBES
   if (cfg == 5) return epi_red ? launch_fg<true, 5>(a, s) : launch_fg<false, 5>(a, s);
   if (cfg == 7) return epi_red ? launch_fg<true, 7>(a, s) : launch_fg<false, 7>(a, s);
+#else
+  if (cfg == 5 || cfg == 7 || cfg == kSkinny32v2Cfg) return hipErrorNotSupported;
+#endif
   if (cfg == kSkinny16Cfg || cfg == kSkinny16x16Cfg || cfg == kSkinny32v2Cfg) {
     if (a.N % KBN != 0 || a.K % (2 * KBK) != 0 || a.n_out > 16 || a.Wf == nullptr) return hipErrorInvalidValue;
     const bool deep = (a.tune & IKF_TUNE_DEEP16) != 0 && a.K <= kDeepTiles * KBK;
+#ifdef IKF_PROBES
     if (cfg == kSkinny32v2Cfg) {
       if (deep) return epi_red ? launch_skinny16<true, true, 2, 2>(a, s) : launch_skinny16<false, true, 2, 2>(a, s);
       return epi_red ? launch_skinny16<true, false, 2, 2>(a, s) : launch_skinny16<false, false, 2, 2>(a, s);
     }
+#endif
     if (cfg == kSkinny16Cfg) {
       if (deep) return epi_red ? launch_skinny16<true, true, 2>(a, s) : launch_skinny16<false, true, 2>(a, s);
       return epi_red ? launch_skinny16<true, false, 2>(a, s) : launch_skinny16<false, false, 2>(a, s);

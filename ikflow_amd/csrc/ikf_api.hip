@@ -701,8 +701,22 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
   return ensure_scratch(m, max_rows);
 }
 
+extern "C" int ikf_probes_build(void) {
+#ifdef IKF_PROBES
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_gemm_variant: null model");
+#ifndef IKF_PROBES
+  if (variant == 121 || variant == 163 || variant == 164 || variant == 171 || variant == 106 || variant == 108)
+    return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_gemm_variant(" + std::to_string(variant) + "): a priced-and-rejected form of rounds 2 - 3 (in-launch entry phase, "
+                "one-launch chain for <= 128 rows, tile configurations 5 / 7 / 11) - compiled only into the probes library "
+                "(ikflow_amd/lib/libikflow_amd_probes.so, python -m ikflow_amd.build --probes)");
+#endif
   if (variant >= 110 && variant <= 112) {  // small-batch one-launch form (entry + first contraction): off / auto / forced
     m->fuse_entry = variant - 110;
     return IKF_OK;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/ikflow_amd.h"
+#include "../../include/ikflow_amd_debug.h"
 
 namespace ikf {
 

@@ -17,8 +17,8 @@ class EngineError(RuntimeError):
     pass
 
 
-def _raise(code: int):
-    msg = _lib.last_error()
+def _raise(code: int, lib=None):
+    msg = _lib.last_error(lib)
     if code == _lib.IKF_ERR_NOT_LOADED:
         raise AssertionError(msg)  # the reference asserts (ikflow_solver.py:310-311)
     if code == _lib.IKF_ERR_MISSING_TENSOR:
@@ -26,9 +26,9 @@ def _raise(code: int):
     raise EngineError(f"libikflow_amd status {code}: {msg}")
 
 
-def _check(code: int):
+def _check(code: int, lib=None):
     if code != _lib.IKF_OK:
-        _raise(code)
+        _raise(code, lib)
 
 
 def fold_chain(robot: Robot) -> Tuple[List[Tuple[int, np.ndarray, np.ndarray]], np.ndarray]:
@@ -93,14 +93,18 @@ def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
 class Engine:
     """One ikf_model handle on one device."""
 
-    def __init__(self, layout: FlowLayout, robot: Robot, device):
-        self.lib = _lib.load()
+    def __init__(self, layout: FlowLayout, robot: Robot, device, flavour: str = ""):
+        self.lib = _lib.load(flavour)
+        self.flavour = flavour
         self.layout = layout
         self.robot = robot
         self.device = torch.device("cuda", _dev_index(device))
         self._h = C.c_void_p()
         desc = _make_desc(layout, robot)
-        _check(self.lib.ikf_create(C.byref(desc), self.device.index, C.byref(self._h)))
+        self._ck(self.lib.ikf_create(C.byref(desc), self.device.index, C.byref(self._h)))
+
+    def _ck(self, code: int) -> None:
+        _check(code, self.lib)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -148,7 +152,7 @@ class Engine:
             for a, s in enumerate(v.shape):
                 arr[i].shape[a] = s
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_load_weights(self._h, arr, len(items)))
+            self._ck(self.lib.ikf_load_weights(self._h, arr, len(items)))
         del keep
 
     @property
@@ -156,21 +160,21 @@ class Engine:
         return bool(self.lib.ikf_weights_loaded(self._h))
 
     def reserve(self, max_rows: int) -> None:
-        _check(self.lib.ikf_reserve(self._h, int(max_rows)))
+        self._ck(self.lib.ikf_reserve(self._h, int(max_rows)))
 
     def reserve_exact(self, max_poses: int, max_repeat: int = 10) -> None:
         """Pre-size the exact-IK state (max_poses * max_repeat LM rows) so that generate_exact allocates nothing."""
-        _check(self.lib.ikf_reserve_exact(self._h, int(max_poses), int(max_repeat)))
+        self._ck(self.lib.ikf_reserve_exact(self._h, int(max_poses), int(max_repeat)))
 
     def set_exact_upfront_rows(self, max_rows: int) -> None:
         """Largest worst-case exact-IK row state a call may reserve up front (0: always grow per retry round)."""
-        _check(self.lib.ikf_set_exact_upfront_rows(self._h, int(max_rows)))
+        self._ck(self.lib.ikf_set_exact_upfront_rows(self._h, int(max_rows)))
 
     PRECISIONS = {"f32": 0, "f16x3": 1}
 
     def set_precision(self, mode: str) -> None:
         """"f32": hidden contractions on the exact-f32 MFMA. "f16x3": error-compensated three-product f16 split."""
-        _check(self.lib.ikf_set_precision(self._h, self.PRECISIONS[mode]))
+        self._ck(self.lib.ikf_set_precision(self._h, self.PRECISIONS[mode]))
 
     @property
     def precision(self) -> str:
@@ -179,7 +183,7 @@ class Engine:
     def set_split_guard(self, on: bool) -> None:
         """f16x3 range guard (include/ikflow_amd.h ikf_set_split_guard): on (default) = one 4-byte flag read per call and an
         automatic f32 re-run when a hidden activation left the f16 range; off = no synchronisation, no re-run."""
-        _check(self.lib.ikf_set_split_guard(self._h, 1 if on else 0))
+        self._ck(self.lib.ikf_set_split_guard(self._h, 1 if on else 0))
 
     @property
     def split_fallback_count(self) -> int:
@@ -189,7 +193,7 @@ class Engine:
         return bool(self.lib.ikf_split_overflow_pending(self._h, self._stream()))
 
     def set_gemm_variant(self, variant: int) -> None:
-        _check(self.lib.ikf_set_gemm_variant(self._h, int(variant)))
+        self._ck(self.lib.ikf_set_gemm_variant(self._h, int(variant)))
 
     # -- approximate IK ------------------------------------------------------------------------------
     def generate_approx(self, poses: torch.Tensor, latent: torch.Tensor, clamp: bool, softflow_scale: float = 0.0) -> torch.Tensor:
@@ -203,7 +207,7 @@ class Engine:
             assert poses.ndim == 2 and poses.shape[1] == 7 and poses.shape[0] == n, f"{poses.shape[0]} != {n}"
         out = torch.empty((n, self.layout.ndof), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _check(
+            self._ck(
                 self.lib.ikf_generate_approx(
                     self._h, poses.data_ptr(), 1 if broadcast else 0, latent.data_ptr(), n, 1 if clamp else 0,
                     float(softflow_scale), out.data_ptr(), self._stream(),
@@ -221,7 +225,7 @@ class Engine:
         q = self._q(q)
         out = torch.empty((q.shape[0], 7), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_forward_kinematics(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_forward_kinematics(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
         return out
 
     def pose_error(self, q: torch.Tensor, target_poses: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -231,7 +235,7 @@ class Engine:
         pe = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
         re = torch.empty_like(pe)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_pose_error(self._h, q.data_ptr(), tp.data_ptr(), q.shape[0], pe.data_ptr(), re.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_pose_error(self._h, q.data_ptr(), tp.data_ptr(), q.shape[0], pe.data_ptr(), re.data_ptr(), self._stream()))
         return pe, re
 
     def lm_step(self, target_poses: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
@@ -240,28 +244,28 @@ class Engine:
         assert tp.shape == (q.shape[0], 7)
         out = torch.empty_like(q)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_lm_step(self._h, tp.data_ptr(), q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_lm_step(self._h, tp.data_ptr(), q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
         return out
 
     def jacobian(self, q: torch.Tensor) -> torch.Tensor:
         q = self._q(q)
         out = torch.empty((q.shape[0], 6, self.layout.ndof), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_jacobian(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_jacobian(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
         return out
 
     def clamp_to_joint_limits(self, q: torch.Tensor) -> torch.Tensor:
         q = self._q(q)
         out = torch.empty_like(q)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_clamp_to_joint_limits(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_clamp_to_joint_limits(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
         return out
 
     def joint_limits_exceeded(self, q: torch.Tensor) -> torch.Tensor:
         q = self._q(q)
         out = torch.empty(q.shape[0], dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_joint_limits_exceeded(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_joint_limits_exceeded(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()))
         return out.to(torch.bool)
 
     # -- capsule self-collision (evaluation_utils.calculate_self_collisions mechanism) ------------------------
@@ -274,7 +278,7 @@ class Engine:
             for k in range(3):
                 c.p0[k], c.p1[k] = float(p0[k]), float(p1[k])
         flat = (C.c_int32 * max(2 * len(pairs), 1))(*[int(v) for ab in pairs for v in ab])
-        _check(self.lib.ikf_set_collision_model(self._h, C.cast(arr, C.c_void_p), len(capsules), C.cast(flat, C.c_void_p), len(pairs)))
+        self._ck(self.lib.ikf_set_collision_model(self._h, C.cast(arr, C.c_void_p), len(capsules), C.cast(flat, C.c_void_p), len(pairs)))
         self._has_collision_model = True
 
     def self_collision(self, q: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -283,7 +287,7 @@ class Engine:
         dist = torch.empty(q.shape[0], dtype=torch.float32, device=self.device)
         col = torch.empty(q.shape[0], dtype=torch.uint8, device=self.device)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_self_collision(self._h, q.data_ptr(), q.shape[0], dist.data_ptr(), col.data_ptr(), self._stream()))
+            self._ck(self.lib.ikf_self_collision(self._h, q.data_ptr(), q.shape[0], dist.data_ptr(), col.data_ptr(), self._stream()))
         return dist, col.to(torch.bool)
 
     # -- exact IK ------------------------------------------------------------------------------------
@@ -361,7 +365,7 @@ class Engine:
                 )
         if err:
             raise err[0]
-        _check(code)
+        self._ck(code)
         # latents must outlive the enqueued kernels
         if keep:
             torch.cuda.current_stream(self.device).synchronize()
@@ -380,7 +384,7 @@ class Engine:
         assert tp.ndim == 2 and tp.shape[1] == 7 and sq.shape[0] == n * repeat, (tuple(tp.shape), tuple(sq.shape), repeat)
         sols = torch.empty((n, self.layout.ndof), dtype=torch.float32, device=self.device)
         valid = torch.empty(n, dtype=torch.uint8, device=self.device)
-        _check(self.lib.ikf_refine_exact(self._h, tp.data_ptr(), n, int(repeat), sq.data_ptr(), int(n_lm_steps),
+        self._ck(self.lib.ikf_refine_exact(self._h, tp.data_ptr(), n, int(repeat), sq.data_ptr(), int(n_lm_steps),
                                          float(pos_error_threshold), float(rot_error_threshold), sols.data_ptr(),
                                          valid.data_ptr(), self._stream()))
         return sols, valid.to(torch.bool)
@@ -389,17 +393,17 @@ class Engine:
     def time_gemm(self, rows: int, iters: int) -> float:
         ms = C.c_float(0.0)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_time_gemm(self._h, int(rows), int(iters), C.byref(ms), self._stream()))
+            self._ck(self.lib.ikf_time_gemm(self._h, int(rows), int(iters), C.byref(ms), self._stream()))
         return float(ms.value)
 
     def profile_begin(self) -> None:
-        _check(self.lib.ikf_profile_begin(self._h))
+        self._ck(self.lib.ikf_profile_begin(self._h))
 
     def profile_end(self):
         """-> (number of dominant-kernel launches since profile_begin, sum of their HIP-event durations in ms)"""
         n, ms = C.c_int64(0), C.c_double(0.0)
         with torch.cuda.device(self.device):
-            _check(self.lib.ikf_profile_end(self._h, C.byref(n), C.byref(ms), self._stream()))
+            self._ck(self.lib.ikf_profile_end(self._h, C.byref(n), C.byref(ms), self._stream()))
         self.last_event_overhead_ms = float(self.lib.ikf_profile_event_overhead_ms(self._h))
         return int(n.value), float(ms.value)
 

@@ -77,6 +77,9 @@ class IKFlowSolver:
             warnings.warn("compile_model is ignored: the MI355X engine runs hand-written HIP kernels, nothing is traced.")
         self._model_weights_loaded = False
         self._engine = None  # created on first use, on the device of the inputs
+        # tests / tools only: "probes" binds lib/libikflow_amd_probes.so (the product + the priced-and-rejected forms of rounds 2 - 3);
+        # set before the first call
+        self.library_flavour = ""
         self._precision = "f32"
         self._state_dict_np: Optional[Dict[str, np.ndarray]] = None
         self.ndof = self.robot.ndof
@@ -108,7 +111,7 @@ class IKFlowSolver:
         device = torch.device(config.DEVICE if device is None else device)
         # an index-less "cuda" means torch's current device (what Engine resolves it to)
         if self._engine is None or self._engine.device != torch.device("cuda", _dev_index(device)):
-            eng = Engine(self._layout, self._robot, device)
+            eng = Engine(self._layout, self._robot, device, self.library_flavour)
             if self._state_dict_np is not None:
                 eng.load_state_dict(self._state_dict_np)
             if self._precision != "f32":

@@ -10,6 +10,8 @@
  * `robot.inverse_kinematics_step_levenburg_marquardt` (:205,208) and `robot.clamp_to_joint_limits` (:102).
  * INTEGRATION.md shows that binding.
  *
+ * Measurement / tuning entry points (kernel timing, form selection) are in ikflow_amd_debug.h - not part of this boundary.
+ *
  * Conventions
  *   - plain C types only: no torch / HIP types in signatures; a stream is passed as `void*` (hipStream_t, may be NULL
  *     for the default stream).
@@ -107,15 +109,10 @@ int ikf_weights_loaded(const ikf_model* m);
 
 /* Pre-size the flow scratch for batches of up to max_rows flow rows. */
 ikf_status ikf_reserve(ikf_model* m, int64_t max_rows);
-/* Pre-size the exact-IK state for calls of up to max_poses target poses with repeat counts up to max_repeat
- * (max_poses * max_repeat LM rows), so that ikf_generate_exact allocates nothing.  Without it a call sizes the row state
- * for its own worst case (n * max(repeat_counts) rows) before any work is enqueued while that is at most 32 Mi rows; a
- * larger worst case is not allocated for: the call starts with round 0's rows and a later round grows the state to its
- * measured n_active * repeat rows (between rounds, where the host has just read the count and the stream is idle). */
+/* Pre-size the exact-IK state for max_poses target poses x max_repeat repeats, so that ikf_generate_exact allocates nothing.
+ * Without it a call reserves its own worst case (n * max(repeat_counts) rows) up front while that is at most
+ * ikf_set_exact_upfront_rows rows (default 32 Mi; 0 = never), else it grows per round from the measured survivor count. */
 ikf_status ikf_reserve_exact(ikf_model* m, int64_t max_poses, int max_repeat);
-/* The largest worst-case row state (n * max(repeat_counts) rows) a call may reserve up front on its own; default 32 Mi
- * rows.  0 = never reserve for the worst case: every call starts with round 0's rows and grows per round (memory-constrained
- * callers).  Has no effect on what ikf_reserve_exact has already provided. */
 ikf_status ikf_set_exact_upfront_rows(ikf_model* m, int64_t max_rows);
 
 /* -- approximate IK: replaces IKFlowSolver._run_inference (ikflow_solver.py:85-110) ----------------------- */
@@ -143,10 +140,9 @@ ikf_status ikf_clamp_to_joint_limits(ikf_model* m, const float* d_q, int64_t n, 
 ikf_status ikf_joint_limits_exceeded(ikf_model* m, const float* d_q, int64_t n, uint8_t* d_exceeded_out,
                                      void* stream);
 
-/* Capsule self-collision: the mechanism behind evaluation_utils.calculate_self_collisions (ikflow/evaluation_utils.py:
- * 115-126; the reference delegates to jrl / Klampt, whose collision geometry is not part of this repository - the caller
- * supplies the capsules).  A capsule is a segment p0-p1 with a radius, expressed in the frame that follows an actuated
- * joint: frame 0 = base, frame j + 1 = after actuated joint j (0-based), fixed URDF offsets already folded in.
+/* Capsule self-collision: the mechanism behind evaluation_utils.calculate_self_collisions (ikflow/evaluation_utils.py:115-126;
+ * the reference delegates to jrl / Klampt geometry that is not in this repository - the caller supplies the capsules).  A
+ * capsule is a segment p0-p1 with a radius in the frame that follows an actuated joint (0 = base, j + 1 = after joint j);
  * pairs = 2 * n_pairs capsule indices; a configuration collides when any listed pair is closer than r_a + r_b. */
 typedef struct ikf_capsule {
   int32_t frame;
@@ -162,14 +158,12 @@ ikf_status ikf_set_collision_model(ikf_model* m, const ikf_capsule* h_capsules, 
 ikf_status ikf_self_collision(ikf_model* m, const float* d_q, int64_t n, float* d_min_dist_out, uint8_t* d_colliding_out,
                               void* stream);
 
-/* Model-free helpers of the evaluation path, on the current device.
- * evaluation_utils.pose_errors (ikflow/evaluation_utils.py:37-51): [n x 7] vs [n x 7] -> L2 position error and
- * quaternion geodesic; acos_epsilon < 0 selects the jrl default (1e-7). */
+/* Model-free helpers of the evaluation path, on the current device.  evaluation_utils.pose_errors (evaluation_utils.py:
+ * 37-51): [n x 7] vs [n x 7] -> L2 position error and quaternion geodesic; acos_epsilon < 0 = the jrl default (1e-7). */
 ikf_status ikf_pose_distance(const float* d_poses_a, const float* d_poses_b, int64_t n, float acos_epsilon,
                              float* d_pos_err, float* d_rot_err, void* stream);
-/* evaluation_utils.calculate_joint_limits_exceeded for any limits table (ikflow/evaluation_utils.py:100-112; the
- * reference's own test uses a 3-column table, tests/evaluation_utils_test.py:36-57): d_q [n x n_cols] on the device,
- * h_lower / h_upper [n_cols] on the host, n_cols <= 32; strict inequalities. */
+/* evaluation_utils.calculate_joint_limits_exceeded for any limits table (evaluation_utils.py:100-112; the reference's test
+ * uses 3 columns): d_q [n x n_cols] on the device, h_lower / h_upper [n_cols] on the host, n_cols <= 32; strict. */
 ikf_status ikf_limits_exceeded(const float* d_q, int64_t n, int n_cols, const float* h_lower, const float* h_upper,
                                uint8_t* d_exceeded_out, void* stream);
 
@@ -189,15 +183,12 @@ ikf_status ikf_generate_exact(ikf_model* m, const float* d_target_poses, int64_t
                               ikf_latent_fn latent_fn, void* latent_user, float* d_q_out, uint8_t* d_valid_out,
                               int64_t* h_stats, void* stream);
 
-/* The same retry schedule with the flow taken out (parity runs: "identical seeds in"): round `round`'s seeds come from
- * the callback instead of the flow.  d_active_idx [n_active] (device, int32, ascending) lists the target poses that are
- * still unsolved; the callback returns a DEVICE pointer to [n_active * repeat x ndof] fp32 clamped seeds laid out
- * tile-major (row = r * n_active + j  <->  repeat r of pose d_active_idx[j]; `conditional.repeat((R,1))`, :185).  The
- * stream is idle when the callback runs in rounds > 0 (the count was just read); in round 0 every pose is active.
- * The seeds are read in place by kernels enqueued on `stream` (not copied, not modified): the buffer must stay valid until then.
- * Everything after `self._run_inference` (:188) is exercised: LM iterations (:199-209), validity (:210-211), "highest
- * valid repeat wins" (:217-222), slot order (:224-225), compaction (:231-233) and the retry rounds (:383-408).
- * Needs no weights. */
+/* The same retry schedule with the flow taken out (parity runs on identical seeds): round `round`'s seeds come from the
+ * callback.  d_active_idx [n_active] (device, int32, ascending) lists the still-unsolved poses; the callback returns a DEVICE
+ * pointer to [n_active * repeat x ndof] clamped seeds, tile-major (row = r * n_active + j <-> repeat r of pose
+ * d_active_idx[j]; `conditional.repeat((R,1))`, :185), read in place by kernels enqueued on `stream`.  Exercises everything
+ * behind `self._run_inference` (:188): LM iterations, validity, "highest valid repeat wins", slot order, compaction, retry
+ * rounds (:199-233, :383-408).  Needs no weights. */
 typedef const float* (*ikf_seed_fn)(void* user, int round, int64_t n_active, int repeat, const int32_t* d_active_idx,
                                     int ndof);
 ikf_status ikf_generate_exact_seeded(ikf_model* m, const float* d_target_poses, int64_t n, const int32_t* repeat_counts,
@@ -210,66 +201,25 @@ ikf_status ikf_refine_exact(ikf_model* m, const float* d_target_poses, int64_t n
                             int n_lm_steps, float pos_error_threshold, float rot_error_threshold, float* d_q_out,
                             uint8_t* d_valid_out, void* stream);
 
-/* -- measurement hooks (bench.py / tests) -------------------------------------------------------------------- */
-/* Time `iters` launches of the dominant kernel (the width x width fused Linear+LeakyReLU contraction) on M rows with
- * hipEvents on `stream`; returns average milliseconds per launch in *ms_out. */
-ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float* ms_out, void* stream);
-/* Per-launch timing of the dominant kernel inside real calls: between _begin and _end every hidden-Linear contraction
- * launched by ikf_generate_approx/_exact on `stream` is bracketed by a hipEvent pair; _end synchronises the stream and
- * returns the number of launches and the sum of their elapsed times (ms), each reduced by the elapsed time of an empty
- * event pair calibrated on the same stream. Adds two event records per launch - use it on extra steps, not inside a
- * throughput-timed region. */
-ikf_status ikf_profile_begin(ikf_model* m);
-ikf_status ikf_profile_end(ikf_model* m, int64_t* n_launches, double* total_ms, void* stream);
-/* What an empty hipEvent pair measured on that stream in the last ikf_profile_end (already subtracted per launch). */
-double ikf_profile_event_overhead_ms(const ikf_model* m);
-/* Arithmetic of the hidden Linear contractions (99 % of the FLOPs):
- *   0 = exact f32 on v_mfma_f32_32x32x2_f32 (default);
- *   1 = error-compensated f16 split on v_mfma_f32_32x32x16_f16 (a = hi + lo/2048 for both operands, three products,
- *       fp32 accumulate): measured closer to fp64 than mode 0 (tools/split_probe.hip), ~5x less matrix-pipe time;
- *       Everything else stays fp32 in both modes.  f16 holds magnitudes up to 65504: every kernel that produces a split
- *       operand ORs a flag into a device word when a hidden activation is non-finite or exceeds that range (see
- *       ikf_set_split_guard). */
+/* -- arithmetic of the hidden Linear contractions (99 % of the FLOPs) ---------------------------------------- */
+/*   0 = exact f32 on the f32 matrix instructions (default: the reference's precision);
+ *   1 = opt-in: error-compensated f16 split (a = hi + lo/2048 for both operands, three v_mfma_f32_32x32x16_f16 products,
+ *       fp32 accumulate): measured closer to fp64 than mode 0, ~2x the throughput.  f16 holds magnitudes up to 65504: every
+ *       kernel that produces a split operand flags a hidden activation that is non-finite or beyond that range. */
 ikf_status ikf_set_precision(ikf_model* m, int mode);
 int ikf_get_precision(const ikf_model* m);
-/* Range guard of mode 1.  guard = 1 (default): at the end of every call the engine reads the overflow flag (one 4-byte
- * copy + stream synchronisation); if it is set the whole call is run again on the exact-f32 path, so the caller never
- * sees an out-of-range result, and the event is counted.  guard = 0: no synchronisation and no re-run; the flag keeps
- * accumulating on the device and ikf_split_overflow_pending() reads and clears it (synchronises `stream`). */
+/* Range guard of mode 1.  guard = 1 (default): every call ends by reading the flag (4-byte copy + stream synchronisation) and,
+ * if set, runs again on the exact-f32 path (counted).  guard = 0: no synchronisation, no re-run; the flag accumulates on the
+ * device until ikf_split_overflow_pending() reads and clears it (synchronises `stream`). */
 ikf_status ikf_set_split_guard(ikf_model* m, int guard);
 /* Number of calls re-run on the f32 path because the f16 range was exceeded (guard = 1). */
 int64_t ikf_split_fallback_count(const ikf_model* m);
 /* 1 if an activation left the f16 range since the last check (then cleared), 0 if not; synchronises `stream`. */
 int ikf_split_overflow_pending(ikf_model* m, void* stream);
-const char* ikf_split_kernel_name(void);
-/* Name of the dominant kernel as it appears in a rocprofv3 kernel trace. */
-const char* ikf_dominant_kernel_name(void);
-/* ... of the kernel that carries (most of) a batch of `rows` rows on this handle with its current settings: "k_flow_rowowner" for
- * batches that take the one-launch row-owner form, else the per-layer contraction of the selected precision. */
-const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
 /* Cluster form (workgroups of one launch exchange activations): number of calls in which a wait ran out - a peer workgroup was not
  * resident, i.e. the device is shared or partitioned.  Such a call's rows were recomputed by the row-owner launch queued behind it (the
  * caller's results are valid), and the handle stopped using the form.  Meaningful once the stream of those calls has been synchronised. */
 int64_t ikf_cluster_repairs(ikf_model* m);
-/* Select the flow pipeline (a tuning / test switch; every setting computes the same function):
- *   -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly, 101..108 the fused form with tile
- *   configuration 0..7 forced, 160 with the 16 x 32 small-batch tiles forced; 0..8 the unfused 4-kernel form with that tile variant;
- *   110 / 111 / 112  small-batch one-launch subnet head (entry kernel + first hidden contraction): off / automatic (default) / forced;
- *   120 / 121        next subnet's entry phase inside the preceding launch (row-tile arrival counter): off (default) / on;
- *   130 .. 134       write-through (sc1) activation stores: none / contractions / entry kernel / both / by batch size (default);
- *   150 / 151        batches of <= 128 rows on 16 x 32 tiles (v_mfma_f32_16x16x4_f32): off / on (default)
- *   152 / 153        the 16-row kernels request their whole operand stream up front: off / on (default)
- *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced
- *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced
- *   170 / 171        <= 128 rows: the whole subnet chain in one launch, hand-over between layers inside each XCD: off (default) / on
- *   185 / 186 / 187  cluster form for 257 .. 3327 rows (G = 8 / 4 / 2 workgroups per 16-row tile split the hidden columns and exchange
- *                    activations inside the launch): never / by the cost model (default) / whenever its grid fits; 188: tests - the next
- *                    cluster launch runs one workgroup short (exercises the repair launch)
- *   180 / 181 / 182  row-owner form (ONE launch per call; a workgroup keeps 16 rows on chip through every subnet, weights streamed
- *                    past them; width 1024, coeff_fn_config 3): never / by batch size (default: full rounds of CUs x 16 rows and a
- *                    last partial round of >= 13/16 of one) / always
- * Returns IKF_ERR_BAD_ARGUMENT if unknown. */
-ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 
 #ifdef __cplusplus
 }

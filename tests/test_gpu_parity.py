@@ -19,8 +19,11 @@ DEV = "cuda:0"
 FLOW_TOL = 1e-5
 
 
-def _solver(robot, hp, sd):
+def _solver(robot, hp, sd, flavour=""):
+    """flavour "probes": the handle lives in lib/libikflow_amd_probes.so (-DIKF_PROBES) - the product's kernels plus the priced-and-rejected
+    forms of rounds 2 - 3 (ikf_set_gemm_variant 106 / 108 / 121 / 163 / 164 / 171), kept reproducible there and out of the shipped library."""
     s = IKFlowSolver(hp, robot)
+    s.library_flavour = flavour
     s.load_state_dict_tensors(sd)
     return s
 
@@ -1559,7 +1562,7 @@ def test_in_launch_entry_phase_equals_entry_launches(kw):
     tiles, 32x64 small-batch tiles), at the largest batches they take it for, with ragged last row tiles, repeated (the counters
     are re-zeroed by every call), through the exact path (pose gather), and both match the oracle."""
     robot, hp, lay, sd = custom_model(seed=21, gain=1.5, **kw)
-    s = _solver(robot, hp, sd)
+    s = _solver(robot, hp, sd, flavour="probes")
     eng = s.engine(DEV)
     n_max = 4096
     _, poses = reachable_poses(robot, n_max, 97)
@@ -1611,7 +1614,7 @@ def test_one_launch_chain_equals_per_layer_launches(kw):
     in the same order, so identical bits - at every row-tile count 1 .. 8, ragged last tiles, repeated (the last workgroup out re-zeroes the
     control words), interleaved with batches the chain does not take, single-pose form, exact path; and it matches the oracle."""
     robot, hp, lay, sd = custom_model(seed=77, gain=1.5, **kw)
-    s = _solver(robot, hp, sd)
+    s = _solver(robot, hp, sd, flavour="probes")
     eng = s.engine(DEV)
     n_max = 300
     _, poses = reachable_poses(robot, n_max, 131)
@@ -1686,10 +1689,17 @@ def test_sixteen_row_tiles_for_small_batches(kw):
             eng.set_gemm_variant(151); eng.set_gemm_variant(159); eng.set_gemm_variant(111)
             assert torch.equal(outs[(151, 111)], s.generate_ik_solutions(P, **kw_n).cpu())  # deterministic
         eng.set_gemm_variant(151); eng.set_gemm_variant(111)
-        for forced in (160, 161, 164):  # 16x32 / 16x16 / 32x32-on-16x16x4 tiles forced for a batch that would not pick them
+        for forced in (160, 161):  # 16x32 / 16x16 tiles forced for a batch that would not pick them
             eng.set_gemm_variant(forced)
             got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
             assert ((got - ref).abs() / scale).max().item() <= FLOW_TOL, forced
+        # the 32x32-on-16x16x4 tiles (164: priced and rejected) live in the probes library only; the product refuses the code
+        with pytest.raises(Exception, match="probes library"):
+            eng.set_gemm_variant(164)
+        sp = _solver(robot, hp, sd, flavour="probes")
+        sp.engine(DEV).set_gemm_variant(164)
+        got = sp.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
+        assert ((got - ref).abs() / scale).max().item() <= FLOW_TOL, 164
         eng.set_gemm_variant(100)
         if lay.dim_cond == 8:  # softflow column
             cond = torch.cat([poses[:100], torch.full((100, 1), 0.4)], dim=1)
