@@ -754,8 +754,9 @@ def main():
     chunks = (B + 16383) // 16384  # the per-layer engine processes a call in chunks of <= 16384 rows
     launches_per_step = 1 if row_owner else gemm_layers * chunks
     prof_steps = max(1, min(10, max(2, args.steps), 8000 // launches_per_step))  # the event pool holds 8192 pairs
+    sol_last = sol
     for _ in range(prof_steps):
-        stepper.step()
+        sol_last = stepper.step()
     n_launch, tot_ms = eng.profile_end()
     gemm_ms = tot_ms / max(n_launch, 1)
     if row_owner:
@@ -766,9 +767,12 @@ def main():
         flop_per_launch = prof_steps * gemm_layers * 2.0 * B * layout.width * layout.width / max(n_launch, 1)
     achieved = flop_per_launch / (gemm_ms * 1e-3) / 1e12
     if use_dist:
-        # (after the event-timed steps: every rank's dominant-kernel launch time rides in the proof; same inputs, same bits as `sol`)
+        # (after the event-timed steps: every rank's dominant-kernel launch time rides in the proof; checked on the LAST step's shard -
+        # the same inputs give the same bits from step to step unless the engine changed form in between, which it does once when a GPU
+        # is shared by several processes: a cluster-form wait runs out, the repair launch takes over, the form is switched off)
         stepper.fence()
-        rccl = collective_proof(stepper, sol, rank, world, local_rank, dev, affinity=affinity, kernel_ms=gemm_ms)
+        rccl = collective_proof(stepper, sol_last, rank, world, local_rank, dev, affinity=affinity, kernel_ms=gemm_ms)
+        rccl["cluster_form_repairs"] = eng.cluster_repairs
         assert rccl["gathered_shards_ok"], "a gathered shard does not carry its rank's checksum"
         assert rccl["world_size"] == world
     asked = asked_global_batch(mode, world, B, args.global_batch)  # strong modes: ceil(G / world) rows per rank, the padding is not counted

@@ -133,6 +133,7 @@ struct ikf_model {
   long long exact_upfront_rows = 32LL << 20;  // ikf_set_exact_upfront_rows
   float* ex_q = nullptr;          // [rows][ndof]
   uint8_t* ex_row_valid = nullptr;  // [rows]
+  unsigned* ex_pose_first = nullptr;  // [poses] earliest valid iteration over a pose's repeats in the running round (early-exit hint)
   int* ex_pose_idx = nullptr;     // [poses]
   int* ex_block_scratch = nullptr;  // [2 * compact_blocks(poses)] per-block counts / offsets of the ordered compaction
   int* ex_count = nullptr;        // device
@@ -233,8 +234,9 @@ static void free_exact(ikf_model* m) {
   if (m->ex_row_valid) (void)hipFree(m->ex_row_valid);
   if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
   if (m->ex_block_scratch) (void)hipFree(m->ex_block_scratch);
+  if (m->ex_pose_first) (void)hipFree(m->ex_pose_first);
   m->ex_q = nullptr; m->ex_row_valid = nullptr; m->ex_pose_idx = nullptr;
-  m->ex_block_scratch = nullptr;
+  m->ex_block_scratch = nullptr; m->ex_pose_first = nullptr;
   m->exact_rows = m->exact_poses = 0;
 }
 
@@ -668,9 +670,11 @@ static ikf_status ensure_exact_poses(ikf_model* m, long long poses) {
   if (poses <= m->exact_poses) return IKF_OK;
   if (m->ex_pose_idx) (void)hipFree(m->ex_pose_idx);
   if (m->ex_block_scratch) (void)hipFree(m->ex_block_scratch);
-  m->ex_pose_idx = nullptr; m->ex_block_scratch = nullptr;
+  if (m->ex_pose_first) (void)hipFree(m->ex_pose_first);
+  m->ex_pose_idx = nullptr; m->ex_block_scratch = nullptr; m->ex_pose_first = nullptr;
   m->exact_poses = 0;
   IKF_HIP(hipMalloc(&m->ex_pose_idx, sizeof(int) * (size_t)poses));
+  IKF_HIP(hipMalloc(&m->ex_pose_first, sizeof(unsigned) * (size_t)poses));
   IKF_HIP(hipMalloc(&m->ex_block_scratch, sizeof(int) * 2 * (size_t)(compact_blocks(poses) + 1)));
   m->exact_poses = poses;
   return IKF_OK;
@@ -779,7 +783,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100..107 fused, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on, 158 / 159 16 x 16 tiles for <= 64 rows off / on, 160 / 161 / 164 small-batch tile configurations 9 / 10 / 11 forced, 162 / 163 configuration 11 for 129..256 rows off / on, 170 / 171 one-launch subnet chain for <= 128 rows off / on; see include/ikflow_amd.h)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused by batch size, 101..108 fused with tile configuration 0..7, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on, 158 / 159 16 x 16 tiles for <= 64 rows off / on, 160 / 161 / 164 small-batch tile configurations 9 / 10 / 11 forced, 162 / 163 configuration 11 for 129..256 rows off / on, 170 / 171 one-launch subnet chain for <= 128 rows off / on; see include/ikflow_amd.h)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -941,7 +945,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   // f16x3 mode: its own tile choice; the partial-sum slots follow the kernel that writes them
   // (f16x3 mode, batches that pick the 16-row f32 tiles - <= 128 rows: the exact-f32 kernels are the faster ones there since round 3,
   // 0.43 against 0.46 ms per call, so the mode steps aside; a forced tile configuration keeps the split kernels)
-  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(m->tile_cfg < 0 && (cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg() || cfg == fused_skinny32v2_cfg()));
+  // (also when such a tile configuration is FORCED - ikf_set_gemm_variant 160 / 161 / 164: the split kernels number their tiles differently)
+  const bool split = (m->precision == 1) && m->split_arena != nullptr && !(cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg() || cfg == fused_skinny32v2_cfg());
   int scfg = -1;
   if (split) {
     scfg = (m->tile_cfg >= 0) ? m->tile_cfg : split_pick_cfg(nr, d.width);
@@ -1523,13 +1528,13 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
     }
     // all LM iterations of the round in one launch + one selection (kin_kernels.hip: k_exact_lm_iters)
     IKF_HIP(launch_exact_lm_iters(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, n_lm_steps, d_q_seed, m->ex_q,
-                                  m->ex_row_valid, pos_thr, rot_thr, s));
+                                  m->ex_row_valid, m->ex_pose_first, pos_thr, rot_thr, s));
     IKF_HIP(launch_exact_select_first(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, d_q_out, d_valid_out,
                                       r == 0 ? 1 : 0, s));
     if (h_stats) {
       h_stats[4 * r + 0] = n_active;
       h_stats[4 * r + 1] = rows;
-      h_stats[4 * r + 2] = rows * n_lm_steps;  // upper bound: rows of poses solved early are masked out
+      h_stats[4 * r + 2] = rows * n_lm_steps;  // upper bound: a row stops at its first valid iteration, or once a sibling repeat was valid earlier
     }
   }
   if (h_stats && n_active > 0) {

@@ -340,7 +340,8 @@ hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int nc
 // thresholds, 0 = never; q keeps that iteration's value) and the per-pose selection (earliest iteration, highest repeat within it)
 hipError_t launch_exact_lm_iters(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
                                  int n_steps, const float* q_in /* seeds; may be q */, float* q, uint8_t* row_valid_iter,
-                                 float pos_thr, float rot_thr, hipStream_t s);
+                                 unsigned* pose_first /* [n_active] scratch, or null: no early exit */, float pos_thr, float rot_thr,
+                                 hipStream_t s);
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
                                      const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, int init, hipStream_t s);
 hipError_t launch_all_active(long long n, int* idx_out, int* count_out, hipStream_t s);  // idx = 0 .. n-1, count = n (round 0)

@@ -452,13 +452,15 @@ __global__ __launch_bounds__(64) void k_self_collision(const Chain* __restrict__
 // pick among its valid repeats, and drops the rows of solved poses.  Row-wise that is: a row keeps stepping until IT is valid (its pose is
 // then solved in that iteration at the latest), and a pose is solved in the FIRST iteration in which any of its repeats is valid, by the
 // highest such repeat.  So each row records the iteration at which it first became valid (1-based; 0 = never) and keeps that q; the
-// selection takes the earliest iteration over a pose's repeats and the highest repeat among those.  (A repeat whose pose was solved by a
-// sibling keeps stepping to the end - work the loop form skips, results it never reads.)
+// selection takes the earliest iteration over a pose's repeats and the highest repeat among those.  A repeat stops stepping once a
+// sibling of its pose has been valid at an iteration it has already completed (pose_first[j], an atomicMin over the repeats' first valid
+// iterations, 0xffffffff = none yet): whatever it found later could not be selected - the reference drops such rows from the batch
+// (q[mask] compaction, ikflow_solver.py:231-233).  A hint only: a late or missed update costs iterations, never a result.
 template <int NDOF>
 __global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict__ ch, const float* __restrict__ poses,
                                                         const int* __restrict__ pose_idx, int n_active, int repeat, int n_steps,
                                                         const float* q_in, float* q, uint8_t* __restrict__ row_valid_iter,
-                                                        float pos_thr, float rot_thr) {  // q_in: the seeds (may be q itself)
+                                                        unsigned* pose_first, float pos_thr, float rot_thr) {  // q_in: the seeds (may be q itself)
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= (long long)n_active * repeat) return;
   const int j = (int)(row % n_active);
@@ -466,12 +468,15 @@ __global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict_
   float qv[NDOF];
   load_q<NDOF>(q_in, row, qv);
   int first = 0;
+  const bool siblings = repeat > 1 && pose_first != nullptr;
   for (int it = 0; it < n_steps; ++it) {
+    if (siblings && it > 0 && __hip_atomic_load(pose_first + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= (unsigned)it) break;
     lm_step_row<NDOF>(ch, tgt, qv);
     float pe, re;
     pose_error_f32<NDOF>(ch, qv, tgt, &pe, &re);
     if (pe < pos_thr && re < rot_thr) {  // ikflow_solver.py:211
       first = it + 1;
+      if (siblings) atomicMin(pose_first + j, (unsigned)first);
       break;
     }
   }
@@ -692,13 +697,17 @@ hipError_t launch_self_collision(const Chain* ch, const CollisionModel* cm, int 
   return hipGetLastError();
 }
 hipError_t launch_exact_lm_iters(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
-                                 int n_steps, const float* q_in, float* q, uint8_t* row_valid_iter, float pos_thr, float rot_thr,
-                                 hipStream_t s) {
+                                 int n_steps, const float* q_in, float* q, uint8_t* row_valid_iter, unsigned* pose_first, float pos_thr,
+                                 float rot_thr, hipStream_t s) {
   const long long rows = (long long)n_active * repeat;
   if (rows <= 0) return hipSuccess;
   if (n_steps > 255) return hipErrorInvalidValue;  // (the first-valid iteration is recorded in a byte)
+  if (repeat > 1 && pose_first != nullptr) {  // "no repeat of this pose valid yet"
+    if (hipError_t e = hipMemsetAsync(pose_first, 0xff, sizeof(unsigned) * (size_t)n_active, s); e != hipSuccess) return e;
+  }
   IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iters<ND>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch,
-                                             poses, pose_idx, n_active, repeat, n_steps, q_in, q, row_valid_iter, pos_thr, rot_thr));
+                                             poses, pose_idx, n_active, repeat, n_steps, q_in, q, row_valid_iter,
+                                             repeat > 1 ? pose_first : nullptr, pos_thr, rot_thr));
   return hipGetLastError();
 }
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
