@@ -612,7 +612,10 @@ def committed_call_traffic(tag):
             ks = json.load(f)["kernels"]
         flow = {k: v for k, v in ks.items() if k.startswith("ikf::k_") and "hbm_read_bytes_corrected" in v and "hbm_write_bytes" in v
                 and not any(x in k for x in ("pack", "k_fk", "k_clamp", "k_pose", "k_lm", "k_exact", "k_compact"))}
+        # calls in the pass: one k_flow_finalize per call of the per-layer form, one k_flow_cluster / k_flow_rowowner launch per call otherwise
         calls = sum(v["dispatches"] for k, v in flow.items() if "k_flow_finalize" in k)
+        if not calls:
+            calls = sum(v["dispatches"] for k, v in flow.items() if "k_flow_cluster" in k) or sum(v["dispatches"] for k, v in flow.items() if "k_flow_rowowner" in k)
         if not calls:
             return None, None
         tot = sum((v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]) * v["dispatches"] for v in flow.values())
