@@ -91,10 +91,12 @@ def test_flow_panda_matches_oracle(n, clamp):
     assert e64 <= FLOW_TOL
 
 
-def test_flow_panda_trained_like_gain():
-    """Coupling coefficients of O(1): exercises atan/exp away from 0 (unclamped outputs, relative tolerance)."""
-    robot, hp, lay, sd = panda_model(seed=3, gain=2.0)
-    n = 256
+@pytest.mark.parametrize("gain,n", [(2.0, 256), (2.0, 4096), (2.5, 4096)])
+def test_flow_panda_trained_like_gain(gain, n):
+    """Coupling coefficients of O(1) - last-Linear outputs scaled by `gain`, so atan / exp work away from 0 and the clamp saturates:
+    every row of the batch (256 rows: the per-layer small-batch kernels; 4096: the row-owner launch), unclamped outputs, 1e-5 relative to
+    max(1, |x|) against the fp64 twin (r03 measured 1e-6 there and asserted 2e-5), and no further from it than twice the torch-CPU oracle is."""
+    robot, hp, lay, sd = panda_model(seed=3, gain=gain)
     _, poses = reachable_poses(robot, n, 5)
     lat = latents(n, lay.dim, 6)
     cond = torch.cat([poses, torch.zeros(n, 1)], 1)
@@ -102,11 +104,12 @@ def test_flow_panda_trained_like_gain():
     ref64 = fo.flow_inverse_f64(sd, lay, lat.numpy(), cond.numpy())[:, : lay.ndof]
     s = _solver(robot, hp, sd)
     got = s.generate_ik_solutions(poses.to(DEV), latent=lat.to(DEV), clamp_to_joint_limits=False).cpu()
+    assert bool(torch.isfinite(got).all())
     scale = np.maximum(1.0, np.abs(ref64))
     e64 = (np.abs(got.numpy() - ref64) / scale).max()
     o64 = (np.abs(ref32.numpy() - ref64) / scale).max()
-    print(f"gain2: rel |hip-f64|={e64:.3e} |cpu32-f64|={o64:.3e}")
-    assert e64 <= max(2e-5, 4 * o64)
+    print(f"gain {gain} n={n}: rel |hip-f64|={e64:.3e} |cpu32-f64|={o64:.3e}, max |x| {np.abs(ref64).max():.1f}")
+    assert e64 <= FLOW_TOL and e64 <= 2 * o64 + 1e-6
 
 
 @pytest.mark.parametrize("which,n", [("panda", 500), ("panda", 4096), ("tiny", 300), ("tiny", 5000), ("fetch_arm", 200), ("fetch_arm", 4200)])
