@@ -16,6 +16,7 @@ robot = Panda()
 hp = hparams_for("panda__full__lp191_5.25m")
 lay = layout_from(hp, robot)
 s = IKFlowSolver(hp, robot)
+s.library_flavour = "probes"  # the forms measured here live in lib/libikflow_amd_probes.so (python -m ikflow_amd.build --probes)
 s.load_state_dict_tensors(random_state_dict(lay, robot, 0))
 eng = s.engine(dev)
 

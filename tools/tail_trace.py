@@ -10,8 +10,8 @@ from ikflow_amd.model import hparams_for, layout_from, random_state_dict
 from ikflow_amd.robots import Panda
 dev = torch.device("cuda:0")
 robot = Panda(); hp = hparams_for("panda__full__lp191_5.25m"); lay = layout_from(hp, robot)
-s = IKFlowSolver(hp, robot); s.load_state_dict_tensors(random_state_dict(lay, robot, 0)); eng = s.engine(dev)
-lib = ctypes.CDLL(_lib.LIB_PATH)
+s = IKFlowSolver(hp, robot); s.library_flavour = "probes"; s.load_state_dict_tensors(random_state_dict(lay, robot, 0)); eng = s.engine(dev)
+lib = _lib.load("probes")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 nb = 4096
 buf = torch.zeros(nb * 64, dtype=torch.int64, device=dev)

@@ -8,7 +8,7 @@ from ikflow_amd.model import hparams_for, layout_from, random_state_dict
 from ikflow_amd.robots import Panda
 dev = torch.device("cuda:0")
 robot = Panda(); hp = hparams_for("panda__full__lp191_5.25m"); lay = layout_from(hp, robot)
-s = IKFlowSolver(hp, robot); s.load_state_dict_tensors(random_state_dict(lay, robot, 0)); eng = s.engine(dev)
+s = IKFlowSolver(hp, robot); s.library_flavour = "probes"; s.load_state_dict_tensors(random_state_dict(lay, robot, 0)); eng = s.engine(dev)
 codes = [[int(y) for y in x.split("+")] for x in sys.argv[1].split(",")]  # "160+110" = both codes set
 sizes = [int(x) for x in sys.argv[2].split(",")]
 def t(B, variant, steps):
