@@ -269,7 +269,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Cluster form for batches that cannot fill the chip with one workgroup per 16 rows (<= 2048 rows): the 16 rows of a row tile are owned by
-// G workgroups (G = 2, 4, 8; workgroup b = member b % G of row tile b / G - with the observed placement b -> XCD b % 8 the members of a
+// G workgroups (G = 2, 4, 8, 16, 32 for <= 2048 / 1024 / 512 / 256 / 128 rows; workgroup b = member b % G of row tile b / G - with the observed placement b -> XCD b % 8 the members of a
 // tile sit on different XCDs, so every XCD's L2 pulls only its members' column slices of W).  Member j computes columns [j 1024/G,
 // (j+1) 1024/G) of every hidden layer from the FULL 16 x 1024 input tile in its LDS, streaming only its slice of W (same image, same
 // register ring - never drained by a barrier or an exchange).  The first Linear (13 inputs) is evaluated in full by every member - cheaper
@@ -286,17 +286,24 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
 // order j, j+1, .. (mod G) - a fixed order per output column, so results are reproducible bit for bit, and equal to the row-owner form's
 // to rounding.  Placement-independent; needs all workgroups resident (grid <= CUs, one per CU: the launcher checks); a wait that runs out
 // sets the abort word (every other wait ends) and the host-visible give-up word.
+// G = 16 / 32: a member has fewer 16-column blocks (4 / 2) than waves, so KS = 2 / 4 waves split the k range of a block and their
+// partial accumulators are summed through LDS in share order in the epilogue; these layers wait for the peers at their start (only the
+// first share's groups are the member's own).  (G = 64 was measured and dropped: 0.336 ms at 64 rows against 0.286 with G = 32 on half
+// the chip - its partial-sum exchange reads 63 peers per thread.)
 // ---------------------------------------------------------------------------------------------------------------
 constexpr unsigned kClusterSpinLimit = 1u << 18;   // polls of (s_sleep 1 + one L2-missing load): some 0.1 s - a peer that is not resident
 
 template <int G>
 __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
-  constexpr int NCB = RO_NCB / G;          // 16-column blocks per wave
-  constexpr int NBUF = 2 * G;              // ring slots of NCB float4: 16 float4 per lane in every form
+  constexpr int NBM = RO_KG / G;                     // 16-column blocks of one member's slice (= 16-k groups of its k range)
+  constexpr int KS = NBM >= RO_WAVES ? 1 : RO_WAVES / NBM;   // G >= 16: fewer blocks than waves - KS waves split the k range of a block
+  constexpr int NCB = NBM >= RO_WAVES ? NBM / RO_WAVES : 1;  // 16-column blocks per wave
+  constexpr int KGW = RO_KG / KS;                    // k groups a wave runs per layer
+  constexpr int NBUF = KS > 1 ? (KGW < 16 ? KGW : 16) : 2 * G;   // ring slots of NCB float4: 16 float4 per lane (8 at G = 64)
   constexpr int PF = NBUF - 1;
-  constexpr int N1 = RO_KG / G;            // 16-k groups of one member's slice
-  constexpr int CS = RO_W / G;             // columns per member
-  static_assert(RO_KG % NBUF == 0, "ring length must divide a layer");
+  constexpr int N1 = NBM;                            // 16-k groups of one member's slice
+  constexpr int CS = RO_W / G;                       // columns per member
+  static_assert(KGW % NBUF == 0 && (KGW & (KGW - 1)) == 0, "ring length must divide a wave's share of a layer");
   const RoArgs& a = c.ro;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const tile0 = smem + RO_OFF_TILE0;
@@ -319,13 +326,15 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   const unsigned long long t0_wall = a.trace != nullptr ? wall_clock64() : 0ull;
 
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.stream), 0, a.stream_bytes, 0x00020000);
-  const unsigned cbg0 = (unsigned)j * (64 / G) + (unsigned)wave * NCB;   // first 16-column (16-k) block of this wave
+  const int bw = KS > 1 ? wave % NBM : wave * NCB;   // this wave's first block inside the member's slice
+  const int ks = KS > 1 ? wave / NBM : 0;            // ... and its share of the k range: physical groups [ks KGW, (ks + 1) KGW)
+  const unsigned cbg0 = (unsigned)j * NBM + (unsigned)bw;   // first 16-column (16-k) block of this wave, true index
   const unsigned voff = cbg0 * 1024 + lane * 16;
   const int n_hl = 2 * a.n_sub;             // hidden layers of the call
   // byte offset of the stream group that holds k group i (in this member's rotated order) of hidden layer hl
   auto grp = [&](int hl, int i) -> unsigned {
     hl = hl < n_hl ? hl : n_hl - 1;
-    const unsigned g = (unsigned)(hl >> 1) * RO_SUB_GROUPS + ((hl & 1) ? 3 + RO_KG : 2) + (unsigned)((j * N1 + i) & (RO_KG - 1));
+    const unsigned g = (unsigned)(hl >> 1) * RO_SUB_GROUPS + ((hl & 1) ? 3 + RO_KG : 2) + (unsigned)((j * N1 + ks * KGW + i) & (RO_KG - 1));
     return g * RO_GROUP_BYTES;
   };
   ro_f4 wb[NBUF][NCB];
@@ -451,24 +460,22 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   };
   // the peers' column slices of an exchanged activation -> this workgroup's LDS tile
   auto gather = [&](const __amdgpu_buffer_rsrc_t& rsX, float* tile) {
-    constexpr int PER = RO_ROWS * CS / 4 / (RO_WAVES * 64);   // float4 per thread per peer (8 / G)
-    ro_f4 v[G - 1][PER];
+    constexpr int PEER4 = RO_ROWS * CS / 4;                         // float4 of one peer's slice
+    constexpr int TOTAL = (G - 1) * PEER4;
+    constexpr int NLD = (TOTAL + RO_WAVES * 64 - 1) / (RO_WAVES * 64);   // loads per thread, all in flight together (<= 8)
+    ro_f4 v[NLD];
 #pragma unroll
-    for (int m = 1; m < G; ++m) {
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = t + q * (RO_WAVES * 64);
+      const int m = 1 + idx / PEER4, w4 = idx % PEER4, row = w4 / (CS / 4), c4 = w4 % (CS / 4);
       const int p = (j + m) % G;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int idx = t + q * (RO_WAVES * 64), row = idx / (CS / 4), c4 = idx % (CS / 4);
-        v[m - 1][q] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)((row * RO_W + p * CS + c4 * 4) * 4), 0, /*sc1*/ 16));
-      }
+      if (idx < TOTAL) v[q] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)((row * RO_W + p * CS + c4 * 4) * 4), 0, /*sc1*/ 16));
     }
 #pragma unroll
-    for (int m = 1; m < G; ++m) {
-#pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int idx = t + q * (RO_WAVES * 64), row = idx / (CS / 4), c4 = idx % (CS / 4);
-        *reinterpret_cast<ro_f4*>(tile + row * RO_LDA + m * CS + c4 * 4) = v[m - 1][q];   // member-relative column order
-      }
+    for (int q = 0; q < NLD; ++q) {
+      const int idx = t + q * (RO_WAVES * 64);
+      const int m = 1 + idx / PEER4, w4 = idx % PEER4, row = w4 / (CS / 4), c4 = w4 % (CS / 4);
+      if (idx < TOTAL) *reinterpret_cast<ro_f4*>(tile + row * RO_LDA + m * CS + c4 * 4) = v[q];   // member-relative column order
     }
     ro_barrier();
   };
@@ -477,29 +484,45 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   ro_f4 af[2];
   // LeakyReLU of the accumulators -> own columns of the LDS tile, and (PUB) write-through to the row tile's exchange buffer
 #define RC_EPILOGUE(tile_out, PUB, rsX)                                                                                  \
-  _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) {                                                                \
-    ro_f4 v_ = acc[cb_];                                                                                                 \
-    v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                    \
-    const int col_ = (int)(cbg0 + cb_) * 16 + 4 * lq;                                                                    \
-    *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + (wave * NCB + cb_) * 16 + 4 * lq) = v_;                       \
-    if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((lrow * RO_W + col_) * 4), 0, /*sc1*/ 16); \
+  if constexpr (KS == 1) {                                                                                               \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) {                                                              \
+      ro_f4 v_ = acc[cb_];                                                                                               \
+      v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
+      const int col_ = (int)(cbg0 + cb_) * 16 + 4 * lq;                                                                  \
+      *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + (bw + cb_) * 16 + 4 * lq) = v_;                             \
+      if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((lrow * RO_W + col_) * 4), 0, /*sc1*/ 16); \
+    }                                                                                                                    \
+  } else {  /* the KS waves of a block hold partial sums over their k shares: through LDS, summed in share order */       \
+    *reinterpret_cast<ro_f4*>(red + wave * (RO_ROWS * RO_RS) + lrow * RO_RS + 4 * lq) = acc[0];                          \
+    ro_barrier();                                                                                                        \
+    if (t < NBM * 64) {                                                                                                  \
+      const int b_ = t >> 6, l_ = t & 63, r_ = l_ & 15, q_ = l_ >> 4;                                                    \
+      ro_f4 v_ = *reinterpret_cast<const ro_f4*>(red + b_ * (RO_ROWS * RO_RS) + r_ * RO_RS + 4 * q_);                    \
+      _Pragma("unroll") for (int k_ = 1; k_ < KS; ++k_)                                                                  \
+          v_ += *reinterpret_cast<const ro_f4*>(red + (k_ * NBM + b_) * (RO_ROWS * RO_RS) + r_ * RO_RS + 4 * q_);        \
+      v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
+      *reinterpret_cast<ro_f4*>((tile_out) + r_ * RO_LDA + b_ * 16 + 4 * q_) = v_;                                       \
+      if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((r_ * RO_W + (j * NBM + b_) * 16 + 4 * q_) * 4), 0, /*sc1*/ 16); \
+    }                                                                                                                    \
   }
   // (the LDS tiles hold the columns in MEMBER-RELATIVE order - own slice first, then members j+1, j+2, .. - so the rotated k order is the
   // ascending physical order and every LDS offset of the layer is a compile-time constant)
-#define RC_AFRAG(tile_in, i_) *reinterpret_cast<const ro_f4*>((tile_in) + lrow * RO_LDA + (i_) * 16 + 4 * lq)
+#define RC_AFRAG(tile_in, i_) *reinterpret_cast<const ro_f4*>((tile_in) + lrow * RO_LDA + (ks * KGW + (i_)) * 16 + 4 * lq)
   // a hidden layer, fully unrolled: k groups in the member's rotated order - its own slice first, the peers' after the hand-over
+  // (k split, G >= 16: only the first share's own groups are there before the hand-over - every wave waits at the start of the layer)
+  constexpr int WAIT_AT = KS > 1 ? 0 : N1;
 #define RC_LAYER(hl_, bias_, tile_in, rsXin, e_in, WAIT)                                                                 \
   {                                                                                                                      \
-    _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = bias_[cb_];                                         \
-    af[0] = RC_AFRAG(tile_in, 0);                                                                                        \
-    _Pragma("unroll") for (int i_ = 0; i_ < RO_KG; ++i_) {                                                               \
-      if (WAIT && i_ == N1) {                                                                                            \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = ks == 0 ? bias_[cb_] : ro_f4{0.f, 0.f, 0.f, 0.f};   \
+    if (!(WAIT && WAIT_AT == 0)) af[0] = RC_AFRAG(tile_in, 0);                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < KGW; ++i_) {                                                                 \
+      if (WAIT && i_ == WAIT_AT) {                                                                                       \
         if (!wait_peers(e_in)) return;                                                                                   \
         gather(rsXin, tile_in);                                                                                          \
         af[i_ & 1] = RC_AFRAG(tile_in, i_);                                                                              \
       }                                                                                                                  \
-      RC_ISSUE((i_ + PF) % NBUF, (hl_) + ((i_ + PF) >> 6), (i_ + PF) & (RO_KG - 1))                                      \
-      if (i_ + 1 < RO_KG && !(WAIT && i_ + 1 == N1)) af[(i_ + 1) & 1] = RC_AFRAG(tile_in, i_ + 1);                       \
+      RC_ISSUE((i_ + PF) % NBUF, (hl_) + ((i_ + PF) / KGW), (i_ + PF) % KGW)                                             \
+      if (i_ + 1 < KGW && !(WAIT && i_ + 1 == WAIT_AT)) af[(i_ + 1) & 1] = RC_AFRAG(tile_in, i_ + 1);                    \
       _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                                   \
           _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = RO_MFMA(wb[i_ % NBUF][cb_][c_], af[i_ & 1][c_], acc[cb_]); \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                 \
@@ -557,11 +580,13 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       ro_f4 p4[4];
 #pragma unroll
       for (int cc = 0; cc < 4; ++cc) p4[cc] = ro_f4{0.f, 0.f, 0.f, 0.f};
+      if (ks == 0) {   // (k split: one wave per block of the member's h3 columns)
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const ro_f4 hf = *reinterpret_cast<const ro_f4*>(tile0 + lrow * RO_LDA + (wave * NCB + cb) * 16 + 4 * lq);
+        for (int cb = 0; cb < NCB; ++cb) {
+          const ro_f4 hf = *reinterpret_cast<const ro_f4*>(tile0 + lrow * RO_LDA + (bw + cb) * 16 + 4 * lq);
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) p4[cc] = RO_MFMA(wl[cb][cc], hf[cc], p4[cc]);
+          for (int cc = 0; cc < 4; ++cc) p4[cc] = RO_MFMA(wl[cb][cc], hf[cc], p4[cc]);
+        }
       }
       const ro_f4 p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
       *reinterpret_cast<ro_f4*>(red + wave * (RO_ROWS * RO_RS) + lrow * RO_RS + 4 * lq) = p;
@@ -578,12 +603,18 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       if (!wait_peers(2 * e0 + 2)) return;
       if (t < 256) {
         const int row = t >> 4, o = t & 15;
-        float part[G];
-#pragma unroll
-        for (int m = 0; m < G; ++m) part[m] = m == j ? mine : __hip_atomic_load(P + m * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every member's partial (the own one included: its write-through store was drained above), 16 loads in flight at a time, added in
+        // member order
         float sum = sm[o];   // b_last (zero beyond n_out)
+        constexpr int CH = G < 16 ? G : 16;
 #pragma unroll
-        for (int m = 0; m < G; ++m) sum += part[m];
+        for (int mb = 0; mb < G; mb += CH) {
+          float part[CH];
+#pragma unroll
+          for (int q = 0; q < CH; ++q) part[q] = __hip_atomic_load(P + (mb + q) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int q = 0; q < CH; ++q) sum += part[q];
+        }
         s_sum[row * RO_RS + o] = sum;
       }
       ro_barrier();
@@ -686,7 +717,7 @@ hipError_t launch_flow_rowowner(const RoArgs& a, int nbuf, hipStream_t s) {
 size_t cluster_xbuf_floats(int n_rt) { return (size_t)n_rt * RO_ROWS * RO_W; }
 size_t cluster_sync_bytes(int n_rt, int G) { return (size_t)n_rt * G * (256 * 4 + 32 * 4) + 128; }   // partial sums, epoch words, abort word
 hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups) {
-  static bool done2[64] = {}, done4[64] = {}, done8[64] = {};
+  static bool done2[64] = {}, done4[64] = {}, done8[64] = {}, done16[64] = {}, done32[64] = {};
   // (drop_workgroups > 0: tests of the repair path - the last workgroups are not launched, their row tile's members wait in vain)
   const unsigned grid = (unsigned)c.n_rt * (unsigned)G - (unsigned)(drop_workgroups > 0 ? 1 : 0);
   // epochs and granule tags count from 1 inside a call: everything polled is zeroed in front of it (one memset: pbuf and flags are one block)
@@ -704,6 +735,14 @@ hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_w
     e = ensure_dynamic_lds(k_flow_cluster<8>, RO_LDS_BYTES, done8);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_flow_cluster<8>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  } else if (G == 16) {
+    e = ensure_dynamic_lds(k_flow_cluster<16>, RO_LDS_BYTES, done16);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_cluster<16>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  } else if (G == 32) {
+    e = ensure_dynamic_lds(k_flow_cluster<32>, RO_LDS_BYTES, done32);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_flow_cluster<32>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
   } else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -1100,9 +1100,10 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
 // whatever part of it is used) and the cluster form (G = 8 / 4 / 2: <= 512 / 1024 / 2048 rows at a fixed cost each).  A batch is cut into
 // consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
 // tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
-//   row-owner round 2.82;  cluster 0.53 / 0.86 / 1.55;  per-layer 0.32 / 0.37 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to
-//   64 / 128 / 256 / 512 / 1024 / 2048 / 2560 / 3072 / 4096 rows;  + 0.01 per extra chunk (its launches' boundaries).
-// e.g. 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
+//   row-owner round 2.82;  cluster 0.285 / 0.38 / 0.53 / 0.86 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
+//   per-layer 0.272 / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
+//   2048 / 2560 / 3072 / 4096 rows;  + 0.01 per extra chunk (its launches' boundaries).
+// e.g. 1 -> per-layer; 16 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
 // 3400 -> one row-owner round; 4096 k + r -> k rounds in one row-owner launch + the plan of r.
 struct FlowChunk {
   int form;         // 0 per-layer, 1 row-owner, 2 / 4 / 8 cluster members
@@ -1123,8 +1124,8 @@ static bool cluster_allowed(ikf_model* m) {
   return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
 }
 static double per_layer_cost(long long rows_on_256) {
-  static const struct { long long rows; double ms; } t[] = {{64, 0.32}, {128, 0.37}, {256, 0.52}, {512, 0.71}, {1024, 1.04}, {2048, 1.75},
-                                                            {2560, 2.56}, {3072, 2.62}, {4096, 3.20}};
+  static const struct { long long rows; double ms; } t[] = {{1, 0.272}, {16, 0.305}, {64, 0.316}, {128, 0.367}, {256, 0.52}, {512, 0.71}, {1024, 1.04},
+                                                            {2048, 1.75}, {2560, 2.56}, {3072, 2.62}, {4096, 3.20}};
   for (const auto& e : t)
     if (rows_on_256 <= e.rows) return e.ms;
   return 3.20 * (double)rows_on_256 / 4096.0;
@@ -1137,7 +1138,7 @@ static double plan_tail(long long rows, long long round, bool ro, bool cl, std::
   std::vector<FlowChunk> best_plan{{0, rows}};
   if (ro && 2.82 < best) { best = 2.82; best_plan = {{1, rows}}; }
   if (cl) {
-    static const struct { int G; double ms; } forms[] = {{8, 0.53}, {4, 0.86}, {2, 1.55}};
+    static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
     for (const auto& f : forms) {
       const long long cap = round / f.G;   // rows of a full grid of this form
       if (rows <= cap) {                   // the whole tail in one launch of this form
@@ -1163,7 +1164,7 @@ static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
   const long long round = (long long)m->n_cu * IKF_RO_ROWS;
   if (ro && m->ro_mode == 1) return {{1, rows}};
   if (cl && m->cl_mode == 1 && rows <= round / 2) {  // forced: one launch of the widest form whose grid fits
-    for (int g = 8; g >= 2; g /= 2)
+    for (int g = 32; g >= 2; g /= 2)
       if (rows <= round / g) return {{g, rows}};
   }
   const long long full = ro ? rows / round * round : 0;

@@ -1430,7 +1430,8 @@ def test_cluster_form_matches_oracle_and_the_row_owner_form(kw):
     _, poses = reachable_poses(robot, n_max, 141)
     lat = latents(n_max, lay.dim, 142)
     ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat, clamp=False)
-    for n in (1, 16, 17, 300, 512, 513, 1000, 1024, 1025, 2000, 2048):   # G = 8 up to 512 rows, 4 up to 1024, 2 up to 2048
+    for n in (1, 16, 17, 100, 128, 129, 200, 256, 257, 300, 512, 513, 1000, 1024, 1025, 2000, 2048):   # G = 32 up to 128 rows (k split 4 ways),
+        # 16 up to 256 (2 ways), 8 up to 512, 4 up to 1024, 2 up to 2048
         P, L = poses[:n].to(DEV), lat[:n].to(DEV)
         kw_n = dict(n=(1 if n == 1 else None), latent=L, clamp_to_joint_limits=False)
         eng.set_gemm_variant(187)
@@ -1477,7 +1478,8 @@ def test_cluster_form_default_split_and_many_calls_in_flight():
     _, poses = reachable_poses(robot, n, 17)
     lat = latents(n, lay.dim, 18)
     P, L = poses.to(DEV), lat.to(DEV)
-    assert "cluster" in eng.dominant_kernel_name(512) and "rowowner" in eng.dominant_kernel_name(n) and "gemm" in eng.dominant_kernel_name(128)
+    assert "cluster" in eng.dominant_kernel_name(512) and "rowowner" in eng.dominant_kernel_name(n) and "gemm" in eng.dominant_kernel_name(1)
+    assert "cluster" in eng.dominant_kernel_name(128) and "cluster" in eng.dominant_kernel_name(16)
     eng.profile_begin()
     full = s.generate_ik_solutions(P, latent=L)
     n_launch, _ = eng.profile_end()
@@ -1486,7 +1488,7 @@ def test_cluster_form_default_split_and_many_calls_in_flight():
     ro = s.generate_ik_solutions(P, latent=L)
     eng.set_gemm_variant(181)
     assert torch.equal(full[:4096], ro[:4096]) and (full[4096:] - ro[4096:]).abs().max().item() <= FLOW_TOL
-    sizes = [512, 300, 1024, 2048, 700, 512]
+    sizes = [512, 300, 1024, 2048, 700, 512, 100, 16, 200]
     first = {k: s.generate_ik_solutions(P[:k], latent=L[:k]).clone() for k in set(sizes)}
     outs = []
     for i in range(200):
@@ -1526,8 +1528,9 @@ def test_cluster_form_repair_launch_when_a_peer_never_arrives():
 
 
 def test_row_owner_form_is_what_the_baseline_batch_runs():
-    """By default a batch's full rounds of (CUs x 16) rows and a last partial round of >= 13/16 of one take the row-owner launch, the
-    rest the per-layer kernels: 4096 rows = one launch, 4096 + 200 = one launch + a 200-row per-layer chunk; results are those of the
+    """By default a batch's full rounds of (CUs x 16) rows (and a last partial round when that is the cheapest plan) take the row-owner
+    launch, the rest the cheapest mix of cluster launches and per-layer kernels (plan_flow): 4096 rows = one launch; 4096 + 200 = one launch
+    + a 200-row cluster chunk (G = 16); with the cluster form off (185) + the per-layer kernels for the 200 rows.  Results are those of the
     forced forms row for row (identical bits with the form that ran them)."""
     robot, hp, lay, sd = panda_model()
     s = _solver(robot, hp, sd)
@@ -1538,17 +1541,23 @@ def test_row_owner_form_is_what_the_baseline_batch_runs():
     P, L = poses.to(DEV), lat.to(DEV)
     eng.set_gemm_variant(182)
     ro = s.generate_ik_solutions(P, latent=L)
-    eng.set_gemm_variant(180)
+    eng.set_gemm_variant(180); eng.set_gemm_variant(185)
     layered_tail = s.generate_ik_solutions(P[4096:], latent=L[4096:])
-    eng.set_gemm_variant(181)
+    eng.set_gemm_variant(187)
+    cluster_tail = s.generate_ik_solutions(P[4096:], latent=L[4096:])
+    eng.set_gemm_variant(181); eng.set_gemm_variant(186)
     auto = s.generate_ik_solutions(P, latent=L)
     assert torch.equal(auto[:4096], ro[:4096])
-    assert torch.equal(auto[4096:], layered_tail)
+    assert torch.equal(auto[4096:], cluster_tail)
+    eng.set_gemm_variant(185)
+    auto_no_cluster = s.generate_ik_solutions(P, latent=L)
+    assert torch.equal(auto_no_cluster[:4096], ro[:4096]) and torch.equal(auto_no_cluster[4096:], layered_tail)
+    eng.set_gemm_variant(186)
     eng.profile_begin()
     s.generate_ik_solutions(P[:4096], latent=L[:4096])
     n_launch, _ = eng.profile_end()
     assert n_launch == 1, "4096 rows = one row-owner launch"
-    assert "rowowner" in eng.dominant_kernel_name(4096) and "gemm" in eng.dominant_kernel_name(128)
+    assert "rowowner" in eng.dominant_kernel_name(4096) and "gemm" in eng.dominant_kernel_name(1)
 
 
 @pytest.mark.parametrize("kw", [

@@ -36,11 +36,11 @@ for rows in rows_list:
             eng.set_gemm_variant(variant)
         reps = max(5, min(50, int(200e3 / rows)))
         for _ in range(3):
-            solver.generate_ik_solutions(p, latent=l)
+            solver.generate_ik_solutions(p, n=(1 if rows == 1 else None), latent=l)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for _ in range(reps):
-            solver.generate_ik_solutions(p, latent=l)
+            solver.generate_ik_solutions(p, n=(1 if rows == 1 else None), latent=l)
         torch.cuda.synchronize(dev)
         rec[name + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
     eng.set_gemm_variant(181)
