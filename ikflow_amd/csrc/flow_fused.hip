@@ -281,142 +281,23 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
   IKF_TSTAMP(3)
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// The next subnet's entry phase in the tail of the launch that produced its pending coupling (TailSync, ikf_internal.h).
-// Called by every thread of a workgroup that has just stored its partial-sum slots of rows [m0, m0 + R) WRITE-THROUGH
-// (16-byte sc1 stores).  Protocol (placement-independent; cdna_hip_programming.md, Guideline 16, form R1 with an arrival
-// counter as the flag): every storing wave drains its stores, barrier, one lane adds 1 to the row tile's agent-scope
-// counter; one wave polls the counter (relaxed agent-scope loads, s_sleep between polls, bounded); barrier; the slots of
-// ALL column tiles are read with agent-scope loads.  Then exactly k_subnet_entry's arithmetic: the pending coupling of the R
-// rows (every sibling repeats it - 2 * R * 16 sums), the new state published by the first column tile, and this workgroup's
-// BNW columns of the first Linear + LeakyReLU -> h_out.  `smem`: 3 * R * ROWBUF + 17 * BNW floats, free for reuse.
-// ---------------------------------------------------------------------------------------------------------------
+// The next subnet's entry phase in the tail of a contraction (TailSync: tail_next_entry) and the one-launch subnet chain for <= 128 rows
+// (k_flow_chain16) - priced and rejected in round 3 (DESIGN_LOG.md section A) - live in flow_fused_probes.inc and exist only in the probes
+// library (-DIKF_PROBES).  The FUSE template parameter of the two contraction kernels below is never instantiated true in the product.
 constexpr unsigned kTailSpinLimit = 1u << 21;  // x (s_sleep 8 + one load) ~ a second: only reached when a sibling never runs
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void store16_wt(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off, floatx4 v) {  // write-through
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uintx4, v), rs, byte_off, 0, /*aux: sc1*/ 16);
 }
-
+#ifdef IKF_PROBES
+#define IKF_PROBES_PART 1
+#include "flow_fused_probes.inc"
+#undef IKF_PROBES_PART
+#else
 template <int NT, int R, int BNW>
-__device__ __forceinline__ void tail_next_entry(const EntryArgs& e, const TailSync& ts, float* smem, int tm, int m0, int n0,
-                                                bool first_col_tile, int t) {
-  constexpr int ITEMS = (R * ROWBUF + NT - 1) / NT;
-  constexpr int C4 = BNW / 4;                  // float4 column groups of this workgroup's slice
-  constexpr int WF4 = (ROWBUF + 1) * C4;       // float4 of the staged first-Linear slice: 16 input rows (zero beyond n_in) + bias
-  constexpr int WPT = (WF4 + NT - 1) / NT;
-  float* cat = smem;
-  float* sums = cat + R * ROWBUF;
-  float* U = sums + R * ROWBUF;
-  float* Wl = U + R * ROWBUF;                  // [ROWBUF + 1][BNW]
-  const int M = e.M, D = e.D, n_in = ts.n_in;
-
-  // ---- publish: this workgroup's slots are on their way; once every wave's stores have left, one lane arrives
-  IKF_TSTAMP(43)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // (also: every wave is done with the epilogue's LDS tiles)
-  if (t == 0) __hip_atomic_fetch_add(ts.arrive + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  IKF_TSTAMP(44)
-
-  // ---- everything that does not depend on the siblings is requested before the wait: the first-Linear slice (cold: it is
-  // the NEXT subnet's weight), the pose entries and (inside pending_issue_loads, below) the state rows
-  floatx4 wst[WPT];
-#pragma unroll
-  for (int i = 0; i < WPT; ++i) {
-    const int idx = t + i * NT, k = idx / C4, c4 = idx - k * C4;
-    floatx4 v = {0.f, 0.f, 0.f, 0.f};
-    if (idx < WF4) {
-      if (k < n_in) v = reinterpret_cast<const floatx4*>(e.w1t + (size_t)k * e.width + n0)[c4];
-      else if (k == ROWBUF) {
-        v = reinterpret_cast<const floatx4*>(e.b1 + n0)[c4];
-        if (e.ps.softflow != 0.0f) v += e.ps.softflow * reinterpret_cast<const floatx4*>(e.w1soft + n0)[c4];
-      }
-    }
-    wst[i] = v;
-  }
-  float pose_v[ITEMS];
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int idx = t + it * NT, ur = idx / ROWBUF, uk = idx % ROWBUF;
-    pose_v[it] = 0.f;
-    if (idx < R * ROWBUF && uk >= e.n_x && uk < n_in) {
-      int gr = m0 + ur;
-      gr = gr < M ? gr : M - 1;
-      const long long grow = e.row0 + gr;
-      const long long pm = grow < e.ps.n_mod ? grow : (e.ps.n_mod == 1 ? 0 : grow % e.ps.n_mod);
-      const long long pi = e.ps.idx ? (long long)e.ps.idx[pm] : pm;
-      pose_v[it] = e.ps.poses[pi * e.ps.stride + (uk - e.n_x)];
-    }
-  }
-
-  // ---- wait for the row tile's other column tiles: ONE wave polls ONE word
-  IKF_TSTAMP(45)
-  if (t < 64) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(ts.arrive + tm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ts.target) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > kTailSpinLimit) {  // a sibling is not resident (the launcher sizes the grid so that this cannot happen)
-        if (t == 0) __hip_atomic_store(ts.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < WPT; ++i)
-    if (t + i * NT < WF4) reinterpret_cast<floatx4*>(Wl)[t + i * NT] = wst[i];
-  __syncthreads();
-  IKF_TSTAMP(46)
-
-  // ---- the pending coupling of the R rows, from every column tile's slots
-  PendingLoads<ITEMS> pl;
-  pending_issue_loads<NT, R, true>(e.pend, e.x_src, D, e.L1, m0, M, t, pl);
-  finish_pending_rows<NT, R>(e.pend, pl, D, e.L1, e.clamp, m0, cat, sums, t);
-  IKF_TSTAMP(47)
-#pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int idx = t + it * NT, ur = idx / ROWBUF, uk = idx % ROWBUF;
-    if (idx >= R * ROWBUF) continue;
-    if (first_col_tile && uk < D && m0 + ur < M) e.x_dst[(size_t)(m0 + ur) * D + uk] = cat[ur * ROWBUF + state_src(e.pend, uk)];
-    U[ur * ROWBUF + uk] = uk < e.n_x ? cat[ur * ROWBUF + state_src(e.pend, e.x_off + uk)] : pose_v[it];
-  }
-  __syncthreads();
-  IKF_TSTAMP(48)
-
-  // ---- first Linear + LeakyReLU: C4 column groups x (NT / C4) row groups
-  constexpr int RG = NT / C4, RPT = (R + RG - 1) / RG;
-  const int tc = t % C4, rg = t / C4;
-  if (rg * RPT < R) {
-    floatx4 w[ROWBUF];
-#pragma unroll
-    for (int k = 0; k < ROWBUF; ++k) w[k] = reinterpret_cast<const floatx4*>(Wl + k * BNW)[tc];
-    const floatx4 b = reinterpret_cast<const floatx4*>(Wl + ROWBUF * BNW)[tc];
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(e.h_out, 0, 0x7fffffff, 0x00020000);
-#pragma unroll 4
-    for (int r = rg * RPT; r < rg * RPT + RPT && r < R; ++r) {
-      float u[ROWBUF];
-#pragma unroll
-      for (int q = 0; q < ROWBUF / 4; ++q) {
-        const floatx4 uq = *reinterpret_cast<const floatx4*>(U + r * ROWBUF + q * 4);
-        u[q * 4 + 0] = uq.x; u[q * 4 + 1] = uq.y; u[q * 4 + 2] = uq.z; u[q * 4 + 3] = uq.w;
-      }
-      floatx4 acc = b;
-#pragma unroll
-      for (int k = 0; k < ROWBUF; ++k)
-        if (k < n_in) acc += u[k] * w[k];  // the entry kernel's chain: bias, then k ascending
-      acc.x = acc.x > 0.f ? acc.x : acc.x * e.slope;
-      acc.y = acc.y > 0.f ? acc.y : acc.y * e.slope;
-      acc.z = acc.z > 0.f ? acc.z : acc.z * e.slope;
-      acc.w = acc.w > 0.f ? acc.w : acc.w * e.slope;
-      // h rows are padded to a multiple of 128: unpredicated; write-through, so that nothing is left to flush at the launch's end
-      store16_wt(rsH, (unsigned)(((size_t)(m0 + r) * e.width + n0 + tc * 4) * 4), acc);
-    }
-  }
-  IKF_TSTAMP(49)
-#ifdef IKF_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  IKF_TSTAMP(50)
+__device__ __forceinline__ void tail_next_entry(const EntryArgs&, const TailSync&, float*, int, int, int, bool, int) {}
 #endif
-}
 constexpr size_t tail_lds_floats(int R, int BNW) { return (size_t)3 * R * ROWBUF + (size_t)(ROWBUF + 1) * BNW; }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1780,90 +1661,10 @@ __global__ __launch_bounds__(KKS * 64) void k_entry_gemm_skinny16(EntryArgs e, F
 //   * The last workgroup to leave zeroes the control words for the next call.
 // ---------------------------------------------------------------------------------------------------------------
 #ifdef IKF_PROBES
-__device__ __forceinline__ unsigned xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }  // HW_REG_XCC_ID
-
-struct XcdWait {
-  const ChainSync* cs;
-  unsigned* arrive;   // this XCD's counter
-  unsigned target;
-  unsigned* s_ok;     // LDS word
-  __device__ __forceinline__ bool operator()() const {
-    if (threadIdx.x == 0) {
-      unsigned ok = 1, n = 0;
-      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(1);
-        if ((++n & 63u) == 0 && (n > kChainSpinLimit || __hip_atomic_load(cs->ctl + IKF_CHAIN_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          ok = 0;
-          break;
-        }
-      }
-      if (!ok) {
-        __hip_atomic_store(cs->ctl + IKF_CHAIN_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cs->give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-  }
-};
-// this workgroup's stores of the phase are in the L2; tell the row tile
-__device__ __forceinline__ void xcd_signal(unsigned* arrive) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // (also: every wave is done with the phase's LDS scratch)
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <bool DEEP>
-__global__ __launch_bounds__(KKS * 64) void k_flow_chain16(const ChainSubnet* __restrict__ tab, int n_sub, ChainCall call, ChainSync cs) {
-  constexpr int NCB = 2, NRB = 1;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ unsigned s_ticket, s_ok;
-  const int t = threadIdx.x;
-  const unsigned xcd = xcc_id();
-  if (t == 0) s_ticket = xcd < IKF_CHAIN_XCDS ? __hip_atomic_fetch_add(cs.ctl + IKF_CHAIN_TICKET + xcd * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffu;
-  __syncthreads();
-  const unsigned ticket = s_ticket;
-  if (ticket >= (unsigned)IKF_CHAIN_PER_XCD) {  // not the placement the launcher verified: nobody may wait for this row tile's full count
-    if (t == 0) {
-      __hip_atomic_store(cs.ctl + IKF_CHAIN_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(cs.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  } else if ((int)xcd < cs.row_tiles) {
-    const int tm = (int)xcd, tn = (int)ticket;
-    unsigned* arrive = cs.ctl + IKF_CHAIN_ARRIVE + xcd * 32;
-    unsigned phase = 0;
-    for (int sidx = 0; sidx < n_sub; ++sidx) {
-      EntryArgs e = tab[sidx].e;
-      FusedGemmArgs g0 = tab[sidx].g[0], g1 = tab[sidx].g[1];
-      e.ps = call.ps; e.row0 = call.row0; e.M = call.M;
-      if (sidx == 0) e.x_src = call.x0;
-      g0.M = call.M; g1.M = call.M;
-      // head: pending coupling of the previous subnet (its partial sums: phase `phase`), first Linear, first hidden contraction
-      if (!entry_gemm16_body<false, DEEP, NCB, NRB, true>(e, g0, tab[sidx].n_in, tm, tn, smem,
-                                                          XcdWait{&cs, arrive, (unsigned)IKF_CHAIN_PER_XCD * phase, &s_ok})) break;
-      xcd_signal(arrive);
-      ++phase;
-      // second hidden contraction + the last Linear's partial sums
-      if (!gemm16_body<true, DEEP, NCB, NRB, true>(g1, tm, tn, smem, XcdWait{&cs, arrive, (unsigned)IKF_CHAIN_PER_XCD * phase, &s_ok})) break;
-      xcd_signal(arrive);
-      ++phase;
-    }
-  }
-  // the last workgroup out resets the control words (every other one is past its last wait)
-  __syncthreads();
-  if (t == 0) {
-    const unsigned d = __hip_atomic_fetch_add(cs.ctl + IKF_CHAIN_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == gridDim.x - 1)
-      for (int i = 0; i < IKF_CHAIN_CTL_WORDS; ++i) __hip_atomic_store(cs.ctl + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-#undef IKF_MFMA16
-
-// fragment-major image of a [N][K] weight for k_flow_gemm_skinny: float4 index
-//   (((tn32*KT + kt)*KKS + kq)*KKG + kk)*64 + lane  <-  W[tn32*32 + lane%32][kt*128 + kq*KKW + kk*8 + (lane/32)*4 .. +3]
-// (per 32-column tile and k tile: 8 k-slices x 2 MFMA groups x 64 lanes; a wave's fetch for one stage is 2 KB contiguous)
-#endif  // IKF_PROBES
+#define IKF_PROBES_PART 2
+#include "flow_fused_probes.inc"
+#undef IKF_PROBES_PART
+#endif
 __global__ __launch_bounds__(256) void k_wfrag_pack(const float* __restrict__ W, float* __restrict__ out, int N, int K) {
   const size_t f = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= (size_t)N * K / 4) return;

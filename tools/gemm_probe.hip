@@ -6,6 +6,7 @@
 #include <vector>
 #include <cmath>
 #define IKF_TRACE 1
+#define IKF_PROBES 1   // the probes flavour: every measured form, also the rejected ones
 #include "../ikflow_amd/csrc/flow_kernels.hip"
 #include "../ikflow_amd/csrc/flow_fused.hip"
 #include "../ikflow_amd/csrc/flow_split.hip"
