@@ -21,7 +21,7 @@ for V in "default:" "per_layer:--gemm-variant 180" "b512:--batch 512" "b128:--ba
   cp "$(find /tmp/kt_${R}_$TAG -name '*kernel_stats.csv' | head -1)" "$OUT/$NAME"
 done
 # counters: FETCH_SIZE | WRITE_SIZE | SQ set, per regime, each pass a separate run
-for V in "default::k_flow_rowowner" "per_layer:--gemm-variant 180:k_flow_gemm" "b512:--batch 512:k_flow_cluster" "b128:--batch 128:k_flow_gemm_skinny" "b16:--batch 16:k_flow_gemm_skinny" "f16x3:--precision f16x3:k_split_gemm"; do
+for V in "default::k_flow_rowowner" "per_layer:--gemm-variant 180:k_flow_gemm" "b512:--batch 512:k_flow_cluster" "b128:--batch 128:k_flow_cluster" "b16:--batch 16:k_flow_cluster" "f16x3:--precision f16x3:k_split_gemm"; do
   TAG=${V%%:*}; REST=${V#*:}; FLAGS=${REST%%:*}; KERN=${REST#*:}
   i=0; FILES=""
   for C in "FETCH_SIZE" "WRITE_SIZE" "$SQSET"; do
