@@ -1130,32 +1130,39 @@ static double per_layer_cost(long long rows_on_256) {
     if (rows_on_256 <= e.rows) return e.ms;
   return 3.20 * (double)rows_on_256 / 4096.0;
 }
-// cheapest plan for `rows` rows below one row-owner round; returns its cost, appends its chunks
-static double plan_tail(long long rows, long long round, bool ro, bool cl, std::vector<FlowChunk>* out) {
-  if (rows <= 0) return 0.0;
-  const long long on256 = rows * 4096 / round;   // the cost tables are in rows of a 256-CU chip
-  double best = per_layer_cost(on256);
-  std::vector<FlowChunk> best_plan{{0, rows}};
-  if (ro && 2.82 < best) { best = 2.82; best_plan = {{1, rows}}; }
-  if (cl) {
-    static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
-    for (const auto& f : forms) {
-      const long long cap = round / f.G;   // rows of a full grid of this form
-      if (rows <= cap) {                   // the whole tail in one launch of this form
-        if (f.ms < best) { best = f.ms; best_plan = {{f.G, rows}}; }
-      } else {                             // a full launch of this form, then the plan of what is left
-        std::vector<FlowChunk> rest;
-        const double c = f.ms + 0.01 + plan_tail(rows - cap, round, ro, cl, &rest);
-        if (c < best) {
-          best = c;
-          best_plan = {{f.G, cap}};
-          best_plan.insert(best_plan.end(), rest.begin(), rest.end());
+// cheapest plan for `rows` rows below one row-owner round; returns its cost, appends its chunks.  Only the forms of G <= 8 (>= 512 rows
+// per launch) are taken as a full launch in front of a rest - the small forms only for a whole (rest of a) tail - and results are memoised
+// by the remaining row count: a handful of states, a few microseconds per call (an unbounded search over 128-row pieces is exponential).
+struct TailPlan {
+  double cost;
+  std::vector<FlowChunk> chunks;
+};
+static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool cl, std::unordered_map<long long, TailPlan>& memo) {
+  auto it = memo.find(rows);
+  if (it != memo.end()) return it->second;
+  TailPlan best{0.0, {}};
+  if (rows > 0) {
+    const long long on256 = rows * 4096 / round;   // the cost tables are in rows of a 256-CU chip
+    best = TailPlan{per_layer_cost(on256), {{0, rows}}};
+    if (ro && 2.82 < best.cost) best = TailPlan{2.82, {{1, rows}}};
+    if (cl) {
+      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
+      for (const auto& f : forms) {
+        const long long cap = round / f.G;   // rows of a full grid of this form
+        if (rows <= cap) {                   // the whole tail in one launch of this form
+          if (f.ms < best.cost) best = TailPlan{f.ms, {{f.G, rows}}};
+        } else if (f.G <= 8) {               // a full launch of this form, then the plan of what is left
+          const TailPlan rest = plan_tail(rows - cap, round, ro, cl, memo);   // (by value: the map may rehash)
+          const double c = f.ms + 0.01 + rest.cost;
+          if (c < best.cost) {
+            best = TailPlan{c, {{f.G, cap}}};
+            best.chunks.insert(best.chunks.end(), rest.chunks.begin(), rest.chunks.end());
+          }
         }
       }
     }
   }
-  out->insert(out->end(), best_plan.begin(), best_plan.end());
-  return best;
+  return memo.emplace(rows, std::move(best)).first->second;
 }
 static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
   std::vector<FlowChunk> plan;
@@ -1173,7 +1180,10 @@ static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
     if (ro && m->ro_min_tail >= 0) {  // (probes: an explicit threshold for the last partial round)
       if (rows - full >= m->ro_min_tail) tail = {{1, rows - full}};
       else tail = {{0, rows - full}};
-    } else plan_tail(rows - full, round, ro, cl, &tail);
+    } else {
+      std::unordered_map<long long, TailPlan> memo;
+      tail = plan_tail(rows - full, round, ro, cl, memo).chunks;
+    }
   }
   if (full > 0) plan.push_back({1, full});
   for (const FlowChunk& c : tail) {
@@ -1243,6 +1253,18 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
   return IKF_OK;
 }
 
+// "rowowner:4096 cluster16:200" - the chunks run_flow would cut a call of `rows` rows into (tests / tools)
+extern "C" ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len) {
+  if (!m || !buf || buf_len < 1) return fail(IKF_ERR_NULL_POINTER, "ikf_plan_describe: null argument");
+  std::string out;
+  for (const FlowChunk& c : plan_flow(m, rows)) {
+    if (!out.empty()) out += " ";
+    out += (c.form == 0 ? std::string("perlayer") : c.form == 1 ? std::string("rowowner") : "cluster" + std::to_string(c.form)) + ":" + std::to_string(c.rows);
+  }
+  if ((int)out.size() + 1 > buf_len) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_plan_describe: buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return IKF_OK;
+}
 extern "C" int64_t ikf_cluster_repairs(ikf_model* m) {
   if (!m) return 0;
   (void)cluster_allowed(m);  // (folds a pending give-up word in)

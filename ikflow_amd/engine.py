@@ -407,6 +407,12 @@ class Engine:
         self.last_event_overhead_ms = float(self.lib.ikf_profile_event_overhead_ms(self._h))
         return int(n.value), float(ms.value)
 
+    def plan(self, rows: int) -> str:
+        """The chunks a call of `rows` rows is cut into, e.g. "rowowner:4096 cluster16:200" (DESIGN.md section 4.3)."""
+        buf = C.create_string_buffer(256)
+        self._ck(self.lib.ikf_plan_describe(self._h, int(rows), buf, 256))
+        return buf.value.decode()
+
     @property
     def cluster_repairs(self) -> int:
         """Calls whose cluster-form launch gave up waiting for a peer workgroup (recomputed by the repair launch; form then disabled)."""

@@ -1527,6 +1527,36 @@ def test_cluster_form_repair_launch_when_a_peer_never_arrives():
     assert (again - good).abs().max().item() <= FLOW_TOL and eng.cluster_repairs == 1
 
 
+def test_plan_of_a_call_by_batch_size():
+    """plan_flow's decisions at representative sizes (released Panda shape, 256 CUs): what DESIGN.md section 4.0 tabulates.  Other shapes
+    (TINY: width 256) and the f16x3 mode stay on the per-layer kernels whatever the size."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    want = {1: "perlayer:1", 8: "cluster32:8", 16: "cluster32:16", 128: "cluster32:128", 200: "cluster16:200", 256: "cluster16:256", 300: "cluster8:300",
+            512: "cluster8:512", 600: "cluster8:512 cluster32:88", 1024: "cluster4:1024", 1536: "cluster8:512 cluster4:1024", 2048: "cluster2:2048",
+            2560: "cluster8:512 cluster2:2048", 3072: "cluster4:1024 cluster2:2048", 3400: "rowowner:3400", 4096: "rowowner:4096",
+            4096 + 200: "rowowner:4096 cluster16:200", 8192: "rowowner:8192", 3 * 4096 + 3500: "rowowner:15788",
+            1_000_000 // 8: "rowowner:122880 cluster2:2048 cluster32:72"}
+    import time
+
+    t0 = time.perf_counter()
+    for n in range(1, 4096, 37):   # the plan of a call is made on the host in front of every call: a few microseconds, whatever the tail
+        eng.plan(n)
+    assert (time.perf_counter() - t0) / 111 < 2e-3
+    got = {n: eng.plan(n) for n in want}
+    assert got == want, {n: (got[n], want[n]) for n in want if got[n] != want[n]}
+    eng.set_gemm_variant(185)
+    assert eng.plan(512) == "perlayer:512" and eng.plan(4096 + 200) == "rowowner:4096 perlayer:200"
+    eng.set_gemm_variant(180)
+    assert eng.plan(4096) == "perlayer:4096"
+    eng.set_gemm_variant(181); eng.set_gemm_variant(186)
+    s.set_precision("f16x3")
+    assert s.engine(DEV).plan(4096) == "perlayer:4096"
+    r2, h2, l2, sd2 = tiny_model()
+    assert _solver(r2, h2, sd2).engine(DEV).plan(4096) == "perlayer:4096"
+
+
 def test_row_owner_form_is_what_the_baseline_batch_runs():
     """By default a batch's full rounds of (CUs x 16) rows (and a last partial round when that is the cheapest plan) take the row-owner
     launch, the rest the cheapest mix of cluster launches and per-layer kernels (plan_flow): 4096 rows = one launch; 4096 + 200 = one launch
