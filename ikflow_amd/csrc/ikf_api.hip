@@ -1148,7 +1148,8 @@ static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool 
     if (cl) {
       static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
       for (const auto& f : forms) {
-        const long long cap = round / f.G;   // rows of a full grid of this form
+        const long long cap = (round / IKF_RO_ROWS) / f.G * IKF_RO_ROWS;   // rows of a full grid of this form: whole tiles, at most one workgroup per CU
+        if (cap <= 0) continue;
         if (rows <= cap) {                   // the whole tail in one launch of this form
           if (f.ms < best.cost) best = TailPlan{f.ms, {{f.G, rows}}};
         } else if (f.G <= 8) {               // a full launch of this form, then the plan of what is left
@@ -1172,7 +1173,7 @@ static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
   if (ro && m->ro_mode == 1) return {{1, rows}};
   if (cl && m->cl_mode == 1 && rows <= round / 2) {  // forced: one launch of the widest form whose grid fits
     for (int g = 32; g >= 2; g /= 2)
-      if (rows <= round / g) return {{g, rows}};
+      if (rows <= (long long)(m->n_cu / g) * IKF_RO_ROWS) return {{g, rows}};
   }
   const long long full = ro ? rows / round * round : 0;
   std::vector<FlowChunk> tail;
@@ -1287,7 +1288,8 @@ static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, l
   for (const FlowChunk& c : plan) {
     ikf_status st = IKF_OK;
     if (c.form == 1) st = run_flow_rowowner(m, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
-    else if (c.form >= 2) st = run_flow_cluster(m, c.form, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
+    else if (c.form >= 2 && ((c.rows + IKF_RO_ROWS - 1) / IKF_RO_ROWS) * c.form <= m->n_cu)   // (every workgroup of a cluster launch must be resident)
+      st = run_flow_cluster(m, c.form, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
     else {
       st = ensure_scratch(m, c.rows);
       for (long long r0 = r_base; st == IKF_OK && r0 < r_base + c.rows; r0 += m->chunk_rows) {
