@@ -457,6 +457,7 @@ static ikf_status build_frag_weights(ikf_model* m) {
 
 // the row-owner kernel's parameter stream: every subnet's weights in execution order (block NB-1 .. 0, s1 then s2) and, inside a subnet,
 // in the order the kernel consumes them (k_rowowner_pack), plus the small per-subnet table (last-Linear bias, perm_inv, split)
+static ikf_status ensure_cluster_scratch(ikf_model* m, long long rows);
 static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& perm_host) {
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes, n_sub = 2 * NB;
@@ -482,7 +483,8 @@ static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& pe
   }
   IKF_HIP(hipMemcpy(m->d_ro_sub, tab.data(), sizeof(RoSubnet) * n_sub, hipMemcpyHostToDevice));
   IKF_HIP(hipDeviceSynchronize());
-  return IKF_OK;
+  // the cluster form's exchange buffers have one size (8 MB + 1.2 MB): reserved here, so that no call ever allocates for them
+  return ensure_cluster_scratch(m, 1);
 }
 
 extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors) {
