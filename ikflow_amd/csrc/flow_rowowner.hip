@@ -8,7 +8,9 @@
 //     consecutive columns 4 (lane / 16) + r) goes back to the tile as one ds_write_b128 per block;
 //   * every parameter of a subnet reaches the wave through ONE linear stream of 8 KB groups (rowowner_pack below) consumed in order
 //     through a ring of register slots, requested PF groups ahead of use and never drained - not at barriers, not between subnets:
-//       group 0          first Linear  [16 k: x inputs, 7 pose entries, softflow column, zeros, bias at k = 15] x the wave's 128 columns
+//       group 0          first Linear  [16 k slots x the wave's 128 columns]; slot k = 4 q + c feeds MFMA c: c = 0, 1 hold what does not
+//                        depend on the flow state (7 pose entries, bias as an input that is always 1), c = 2, 3 the x inputs and the
+//                        softflow column (ro_input_slot) - the cluster form evaluates the first half while it waits for its peers
 //       group 1 / 66     bias of hidden Linear 2 / 3 in accumulator layout (the accumulators START from it)
 //       group 2..65      hidden Linear 2, 16 k per group            group 67..130  hidden Linear 3
 //       group 131        last Linear, the wave's 128-k slice x 16 outputs (zero rows beyond n_out)
@@ -48,6 +50,18 @@ constexpr int RO_LDS_FLOATS = RO_OFF_SMALL + RO_MAX_SUB * RO_SMALL_WORDS;
 constexpr size_t RO_LDS_BYTES = sizeof(float) * RO_LDS_FLOATS;
 
 static_assert(sizeof(RoSubnet) == RO_SMALL_WORDS * 4, "RoSubnet layout");
+
+// First-Linear input slot k = 4 q + c (component c of lane-quarter q feeds MFMA c): what sits there.
+//   >= 0: pose entry (0..6);  -1: the constant 1 (bias);  -2 - e: x input e (0 .. n_x - 1);  -100: the softflow entry;  -200: nothing (zero)
+__host__ __device__ __forceinline__ int ro_input_slot(int k, int n_x) {
+  const int c = k & 3, q = k >> 2;
+  if (c < 2) {
+    const int s = c * 4 + q;
+    return s < 7 ? s : -1;
+  }
+  const int e = (c - 2) * 4 + q;
+  return e < n_x ? -2 - e : (e == n_x ? -100 : -200);
+}
 
 __device__ __forceinline__ void ro_barrier() {
   // LDS traffic of this wave done, then the workgroup barrier; the weight-stream loads stay in flight
@@ -145,10 +159,12 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
       const int row = (t - 256) >> 4, k = t & 15;
       const int* ni = reinterpret_cast<const int*>(nxt_sm);
       const int n_x = ni[33], x_off = ni[34];
+      const int what = ro_input_slot(k, n_x);
       float v = 0.f;
-      if (k < n_x) v = ro_new_state(xs_old, red, pend_sm, row, x_off + k, a.L1, a.clamp);
-      else if (k < n_x + 8) v = cond[row * 8 + (k - n_x)];
-      else if (k == 15) v = 1.0f;
+      if (what >= 0) v = cond[row * 8 + what];
+      else if (what == -1) v = 1.0f;
+      else if (what == -100) v = cond[row * 8 + 7];
+      else if (what > -100) v = ro_new_state(xs_old, red, pend_sm, row, x_off + (-2 - what), a.L1, a.clamp);
       us[row * RO_US + k] = v;
     }
   };
@@ -413,16 +429,27 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       const int row = (t - 256) >> 4, k = t & 15;
       const int* ni = reinterpret_cast<const int*>(nxt_sm);
       const int n_x = ni[33], x_off = ni[34];
+      const int what = ro_input_slot(k, n_x);
       float v = 0.f;
-      if (k < n_x) v = new_state(pend_sm, xs_old, row, x_off + k);
-      else if (k < n_x + 8) v = cond[row * 8 + (k - n_x)];
-      else if (k == 15) v = 1.0f;
+      if (what >= 0) v = cond[row * 8 + what];
+      else if (what == -1) v = 1.0f;
+      else if (what == -100) v = cond[row * 8 + 7];
+      else if (what > -100) v = new_state(pend_sm, xs_old, row, x_off + (-2 - what));
       us[row * RO_US + k] = v;
     }
   };
   advance(nullptr, small, xs, xs + 256);
   ro_barrier();
   int xcur = 1;
+  // the state-independent half of a first Linear (the current w1): pose entries and the bias input never change during a call
+  ro_f4 a1[RO_NCB];
+  const ro_f4 uf_static = *reinterpret_cast<const ro_f4*>(us + lrow * RO_US + 4 * lq);   // (.x, .y are used)
+#define RC_FIRST_STATIC                                                                                  \
+  {                                                                                                      \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) a1[cb_] = RO_MFMA(w1[cb_][0], uf_static[0], (ro_f4{0.f, 0.f, 0.f, 0.f})); \
+    _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) a1[cb_] = RO_MFMA(w1[cb_][1], uf_static[1], a1[cb_]);                     \
+  }
+  RC_FIRST_STATIC
 
   // ---- hand-over primitives
   // this workgroup's payload stores are issued: drain them (every storing wave), then ONE lane publishes the epoch
@@ -543,15 +570,13 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     small_load(s, 1, b2);
     small_load(s, 2 + RO_KG, b3);
     small_load(s, RO_SUB_GROUPS - 1, wl);
-    // ---- first Linear + LeakyReLU, ALL 1024 columns (every member repeats it: 32 MFMAs per wave against an exchange) -> tile0,
-    //      stored in member-relative column order
+    // ---- first Linear + LeakyReLU, ALL 1024 columns (every member repeats it: cheaper than an exchange) -> tile0, stored in
+    //      member-relative column order.  Its state-independent half (pose entries, bias: MFMA 0, 1) is already in a1 - evaluated while
+    //      the previous subnet's partial sums were in flight; what is left is the x / softflow half (MFMA 2, 3)
     {
       const ro_f4 uf = *reinterpret_cast<const ro_f4*>(us + lrow * RO_US + 4 * lq);
-      ro_f4 a1[RO_NCB];
 #pragma unroll
-      for (int cb = 0; cb < RO_NCB; ++cb) a1[cb] = ro_f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
+      for (int cc = 2; cc < 4; ++cc)
 #pragma unroll
         for (int cb = 0; cb < RO_NCB; ++cb) a1[cb] = RO_MFMA(w1[cb][cc], uf[cc], a1[cb]);
 #pragma unroll
@@ -600,6 +625,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
         __hip_atomic_store(P + j * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       RC_PUBLISH(2 * e0 + 2)
+      RC_FIRST_STATIC   // the next subnet's first Linear, state-independent half, under the exchange's latency (w1 = its weights by now)
       if (!wait_peers(2 * e0 + 2)) return;
       if (t < 256) {
         const int row = t >> 4, o = t & 15;
@@ -665,10 +691,11 @@ __global__ __launch_bounds__(256) void k_rowowner_pack(RoPackArgs p) {
   for (int c = 0; c < 4; ++c) {
     float x = 0.f;
     if (g == 0) {
-      const int col = wave * 128 + cb * 16 + lrow, k = 4 * lq + c;
-      if (k < w.n_x + 7) x = w.w_first_t[(size_t)k * RO_W + col];
-      else if (k == w.n_x + 7) x = w.w_soft[col];
-      else if (k == 15) x = w.b_first[col];
+      const int col = wave * 128 + cb * 16 + lrow, what = ro_input_slot(4 * lq + c, w.n_x);
+      if (what >= 0) x = w.w_first_t[(size_t)(w.n_x + what) * RO_W + col];   // (rows of w_first_t: the x inputs, then the 7 pose entries)
+      else if (what == -1) x = w.b_first[col];
+      else if (what == -100) x = w.w_soft[col];
+      else if (what > -100) x = w.w_first_t[(size_t)(-2 - what) * RO_W + col];
     } else if (g == 1 || g == 2 + RO_KG) {
       x = w.b_mid[g == 1 ? 0 : 1][wave * 128 + cb * 16 + 4 * lq + c];
     } else if (g < RO_SUB_GROUPS - 1) {
@@ -690,7 +717,7 @@ const char* rowowner_kernel_name() { return "k_flow_rowowner"; }
 size_t rowowner_stream_floats(int n_sub) { return ((size_t)n_sub * RO_SUB_GROUPS + 4) * (RO_GROUP_BYTES / 4); }  // + ring lead padding
 bool rowowner_shape_ok(const FlowDims& d, int n_sub) {
   const int nmax = d.L1 > d.L2 ? d.L1 : d.L2;
-  return d.width == RO_W && d.n_hidden == 3 && d.D <= 16 && nmax + 8 <= 15 && 2 * nmax <= 16 && n_sub <= RO_MAX_SUB && d.ndof <= 16;
+  return d.width == RO_W && d.n_hidden == 3 && d.D <= 16 && nmax + 1 <= 8 && 2 * nmax <= 16 && n_sub <= RO_MAX_SUB && d.ndof <= 16;   // (x inputs + softflow: 8 slots)
 }
 hipError_t launch_rowowner_pack(const SubnetWeights& w, float* out, hipStream_t s) {
   RoPackArgs p{w, out};
