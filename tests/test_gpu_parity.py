@@ -1043,6 +1043,53 @@ def test_flow_random_configurations(cfg):
             _FUZZ_STATS["noise_branch"].append(f"{'-'.join(str(v) for v in cfg.values())} {prec} n={n}: {err:.2e} vs fp32 cpu, {err64:.2e} vs fp64, cpu noise {cpu_noise:.2e}")
 
 
+def _random_resident_configs(count, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        robot_name = str(rng.choice(["panda", "fetch", "fetch_arm"]))
+        ndof = O(robot_name).ndof
+        out.append(dict(nb_nodes=int(rng.integers(1, 4)), dim=int(rng.integers(ndof, 15)), n_hidden=3, width=int(rng.choice([1024, 1024, 1000, 900])),
+                        robot_name=robot_name, softflow=bool(rng.integers(0, 2)), sigmoid=bool(rng.integers(0, 4) == 0), seed=int(rng.integers(0, 1000)),
+                        gain=float(rng.choice([1.0, 1.5, 2.0])),
+                        n=int(rng.choice([7, 8, 15, 16, 17, 120, 129, 255, 300, 511, 513, 777, 1024, 1500, 2047, 2049, 2600, 3327, 3500, 4096, 4111, 4500, 8200])),
+                        clamp=bool(rng.integers(0, 2)), single_pose=bool(rng.integers(0, 5) == 0), soft=float(rng.choice([0.0, 0.0, 0.3]))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_resident_configs(int(os.environ.get("IKF_FUZZ_RESIDENT_COUNT", "32")), int(os.environ.get("IKF_FUZZ_SEED", "20260928"))),
+                         ids=lambda c: "-".join(str(v) for v in c.values()))
+def test_resident_row_forms_random_configurations(cfg):
+    """Seeded random draws over what the row-owner launch and the cluster form accept (width padded to 1024, coeff_fn_config 3; any robot, depth,
+    dim_latent_space up to 14 - i.e. up to 7 x inputs per subnet -, softflow on / off with a non-zero entry, sigmoid_on_output, the single-pose
+    form) at row counts on both sides of every plan boundary (8 / 128 / 256 / 512 / 1024 / 2048 / ~3300 / 4096 rows): the default plan
+    (whatever mix of forms it is) against the oracle, every row."""
+    cfg = dict(cfg)
+    n, clamp, single, soft = cfg.pop("n"), cfg.pop("clamp"), cfg.pop("single_pose"), cfg.pop("soft")
+    if cfg["sigmoid"] and cfg["softflow"]:
+        cfg["softflow"] = False   # (the reference refuses the combination, tested in test_flow_random_configurations)
+    robot, hp, lay, sd = custom_model(**cfg)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    _, poses = reachable_poses(robot, n, cfg["seed"] + 1)
+    if single:
+        poses = poses[:1].expand(n, 7).contiguous()
+    lat = latents(n, lay.dim, cfg["seed"] + 2)
+    soft = soft if lay.dim_cond == 8 else 0.0
+    cond = torch.cat([poses, torch.full((n, 1), soft)], 1) if lay.dim_cond == 8 else poses
+    ref = fo.run_inference_torch(sd, lay, robot, lat, cond, clamp)
+    ref64 = torch.from_numpy(fo.run_inference_f64(sd, lay, robot, lat.numpy(), cond.numpy(), clamp)).float()
+    scale = torch.clamp(ref64.abs(), min=1.0)
+    cpu_noise = ((ref - ref64).abs() / scale).max().item()
+    got = eng.generate_approx((poses[0] if single else poses).to(DEV), lat.to(DEV), clamp, softflow_scale=soft).cpu()
+    assert got.shape == ref.shape and bool(torch.isfinite(got).all())
+    err = ((got - ref).abs() / scale).max().item()
+    err64 = ((got - ref64).abs() / scale).max().item()
+    plan = eng.plan(n)
+    assert plan != f"perlayer:{n}" or n < 8, plan   # (these shapes are the resident-row forms' domain)
+    assert err <= FLOW_TOL or err64 <= 4 * cpu_noise, f"{cfg} n={n} plan {plan}: {err:.2e} vs fp32, {err64:.2e} vs fp64 (cpu {cpu_noise:.2e})"
+
+
 def test_flow_random_configurations_share_of_ill_conditioned_cases():
     """The fuzz cases above may pass on `err64 <= 4 * cpu_noise` when the fp32 CPU path itself is further than 1e-5 from fp64 (gain-2.5
     random weights).  That branch must stay the exception: report every case that took it, fail above 10 % of the runs."""
