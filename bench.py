@@ -100,6 +100,8 @@ class ShardedStepper:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self.comm_stream.wait_event(ev)
+                if TEST_BACKEND == "gloo":  # tests only: gloo's host staging does not reliably wait for the stream it is issued on (ikflow_amd/dist.py)
+                    ev.synchronize()
                 with torch.cuda.stream(self.comm_stream):
                     dist.all_gather_into_tensor(self.gathered[k], sol)
                 sol.record_stream(self.comm_stream)

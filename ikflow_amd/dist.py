@@ -37,6 +37,11 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     pad = torch.zeros((rows_max,) + tuple(cols), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * rows_max,) + tuple(cols), dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo stages device tensors through the host on its own streams; on this ROCm build that staging copy was seen to start before
+        # the work queued on the current stream had finished (stale rows in 1 of 8 runs of the two-ranks-on-one-GPU test) - with gloo
+        # (tests only: RCCL orders its kernels behind the current stream itself) the producer stream is drained first
+        torch.cuda.current_stream(local.device).synchronize()
     dist.all_gather_into_tensor(out, pad, group=group)
     if n_total == world * rows_max:
         return out
