@@ -206,14 +206,23 @@ def collective_proof(stepper, sol, rank, world, local_rank, dev, affinity=None, 
     full = stepper.last_gathered()
     own = sol.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
     sums = torch.empty(world, dtype=torch.int64, device=sol.device)
+
+    def drain():  # tests only (gloo with device tensors): its host staging does not reliably wait for the producer stream (ikflow_amd/dist.py)
+        if sol.is_cuda and dist.get_backend() == "gloo":
+            torch.cuda.synchronize(sol.device)
+
+    drain()
     dist.all_gather_into_tensor(sums, own)
     ok = bool(torch.equal(full[rank * B : (rank + 1) * B], sol))
     for r in range(world):
         ok = ok and int(full[r * B : (r + 1) * B].contiguous().view(torch.int32).to(torch.int64).sum().item()) == int(sums[r].item())
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=sol.device)
+    drain()
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     times = torch.empty(world, dtype=torch.float64, device=sol.device)
-    dist.all_gather_into_tensor(times, torch.tensor([stepper.local_elapsed], dtype=torch.float64, device=sol.device))
+    mine_t = torch.tensor([stepper.local_elapsed], dtype=torch.float64, device=sol.device)
+    drain()
+    dist.all_gather_into_tensor(times, mine_t)
     me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
     if affinity is not None:
         me["affinity"] = affinity
