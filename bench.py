@@ -140,6 +140,8 @@ def timed_steps(stepper, steps, warmup):
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], device=stepper.device, dtype=torch.float64)
+        if t.is_cuda and dist.get_backend() == "gloo":  # tests only: see collective_proof
+            torch.cuda.synchronize(t.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, sol
