@@ -173,6 +173,11 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
   int xcur = 1;   // xs + 256 * xcur holds the current state
 
   ro_f4 acc[RO_NCB];
+  // Odd k groups accumulate into a second set: two half-length f32 chains per output, added at the end, instead of one chain of 1024
+  // products (+ bias).  Rounding error grows with the chain length: measured over every row of the baseline batches the distance to the
+  // oracle drops from 4.05e-6 to 2.86e-6 rad (Panda, 4096 rows) and from 8.1e-6 to 3.4e-6 relative with O(1) coupling coefficients (last
+  // Linear x 2.5) - at the same speed (28 more registers, the same MFMAs).
+  ro_f4 accb[RO_NCB];
   ro_f4 af[2];
 #define RO_EPILOGUE(tile_out)                                                                                            \
   _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) {                                                             \
@@ -182,12 +187,13 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
   }
 #define RO_AFRAG(tile_in, kg) *reinterpret_cast<const ro_f4*>((tile_in) + lrow * RO_LDA + (kg) * 16 + 4 * lq)
   // one 16-k group: request the group PF ahead into the slot consumed last, read the next A fragment, 32 MFMAs
+#define RO_ACC(par) ((par) ? accb : acc)
 #define RO_KGSTEP(slot, tile_in, kg, par)                                                                                \
   {                                                                                                                      \
     RO_ISSUE(((slot) + PF) % NBUF)                                                                                       \
     af[(par) ^ 1] = RO_AFRAG(tile_in, (kg) + 1);                                                                         \
     _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                                     \
-        _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) acc[cb_] = RO_MFMA(wb[slot][cb_][c_], af[par][c_], acc[cb_]);  \
+        _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) RO_ACC(par)[cb_] = RO_MFMA(wb[slot][cb_][c_], af[par][c_], RO_ACC(par)[cb_]);  \
     /* pinned order: the A fragment read, then one weight request per four MFMAs */                                      \
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < RO_NCB; ++i_) {                                                              \
@@ -196,15 +202,19 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
     }                                                                                                                    \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
   }
+#define RO_CHAIN_INIT _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) accb[cb_] = ro_f4{0.f, 0.f, 0.f, 0.f};
+#define RO_CHAIN_JOIN _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) acc[cb_] += accb[cb_];
   // a hidden layer: accumulators start from the bias group (slot SB), then 64 groups starting in slot (SB + 1) % NBUF
 #define RO_LAYER(SB, tile_in, tile_out)                                                                                  \
   {                                                                                                                      \
     RO_ISSUE(((SB) + PF) % NBUF)                                                                                         \
     af[0] = RO_AFRAG(tile_in, 0);                                                                                        \
     _Pragma("unroll") for (int cb_ = 0; cb_ < RO_NCB; ++cb_) acc[cb_] = wb[SB][cb_];                                     \
+    RO_CHAIN_INIT                                                                                                        \
     for (int kg = 0; kg < RO_KG; kg += NBUF) {                                                                           \
       _Pragma("unroll") for (int u_ = 0; u_ < NBUF; ++u_) RO_KGSTEP(((SB) + 1 + u_) % NBUF, tile_in, kg + u_, u_ & 1)    \
     }                                                                                                                    \
+    RO_CHAIN_JOIN                                                                                                        \
     RO_EPILOGUE(tile_out)                                                                                                \
     ro_barrier();                                                                                                        \
   }
