@@ -3,7 +3,7 @@
 // host reference of the inverse pass; prints ms per call, shader cycles per subnet (median over the workgroups) against the
 // 2 x 131,072-cycle matrix-pipe floor, and the spread over workgroups.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/rowowner_probe.hip -o tools/bin/rowowner_probe
-//   tools/bin/rowowner_probe [rows=4096] [iters=20] [nbuf=4] [blocks=12] [D=7] [G=1]
+//   tools/bin/rowowner_probe [rows=4096] [iters=20] [nbuf=4] [blocks=12] [D=7] [G=1] [duo=0]
 // G = 2 / 4 / 8: the cluster form (k_flow_cluster<G>: G workgroups per 16-row tile split the hidden columns and exchange activations
 // through global memory) - rows * G / 16 must not exceed the CU count.
 #include <algorithm>
@@ -14,6 +14,7 @@
 #include <random>
 #include <vector>
 #include "../ikflow_amd/csrc/flow_rowowner.hip"
+#include "flow_duo_probe.inc"   // the half-CU cluster form: measured and dropped, kept as a probe
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 using namespace ikf;
@@ -30,6 +31,7 @@ int main(int argc, char** argv) {
   const int NB = argc > 4 ? atoi(argv[4]) : 12;
   const int D = argc > 5 ? atoi(argv[5]) : 7;
   const int G = argc > 6 ? atoi(argv[6]) : 1;
+  const int duo = argc > 7 ? atoi(argv[7]) : 0;   // 1: the half-CU form (k_flow_duo<G>, two workgroups per CU)
   const int L1 = D / 2, L2 = D - L1, W = RO_W, ndof = 7;
   const int n_sub = 2 * NB;
   std::mt19937 rng(7);
@@ -115,7 +117,7 @@ int main(int argc, char** argv) {
     rc.give_up = h_give_up;
   }
   auto launch = [&]() -> hipError_t {
-    if (G > 1) { rc.ro = a; return launch_flow_cluster(rc, G, nullptr); }
+    if (G > 1) { rc.ro = a; return duo ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr); }
     return launch_flow_rowowner(a, nbuf, nullptr);
   };
 #define launch_flow_rowowner(a_, n_, s_) launch()
@@ -174,7 +176,7 @@ int main(int argc, char** argv) {
       max_err = std::max(max_err, fabs(q - (double)hq[(size_t)r * ndof + j]));
     }
   }
-  printf("G %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
+  printf("%sG %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", duo ? "duo " : "", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
   // timing
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) CK(launch_flow_rowowner(a, nbuf, nullptr));
