@@ -687,6 +687,21 @@ def run_cells(solver, eng, robot, layout, dev, precision):
 TEST_BACKEND = os.environ.get("IKF_BENCH_TEST_BACKEND", "")
 
 
+def device_index_for(rank, local_rank, n_visible, env=None):
+    """The device of this rank: cuda:LOCAL_RANK when the node's GPUs are all visible (torch.distributed.run's default), cuda:0 when the
+    launcher narrowed THIS rank's view to its own GPU (one visible device and a *_VISIBLE_DEVICES variable set); anything else is a
+    launch error - one rank per GPU - and says which variable to look at."""
+    env = os.environ if env is None else env
+    vis = next((f"{k}={env[k]}" for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if k in env), None)
+    if n_visible > local_rank:
+        return local_rank
+    if n_visible == 1 and vis is not None:
+        return 0   # (two ranks that were both given the same GPU fail loudly in RCCL's init: it refuses two ranks on one device)
+    raise AssertionError(
+        f"rank {rank}: LOCAL_RANK={local_rank} but only {n_visible} GPU(s) are visible - one rank per GPU: check --nproc-per-node against "
+        f"HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES ({vis or 'unset'})")
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -705,9 +720,7 @@ def main():
             local_rank = 0
             dist.init_process_group(TEST_BACKEND)
         else:
-            assert torch.cuda.device_count() > local_rank, (
-                f"rank {rank}: LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} GPU(s) are visible - one rank per GPU: check "
-                f"--nproc-per-node against HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (={os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('ROCR_VISIBLE_DEVICES', 'unset'))})")
+            local_rank = device_index_for(rank, local_rank, torch.cuda.device_count())
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"

@@ -108,8 +108,13 @@ def test_bench_refuses_more_ranks_than_visible_gpus_with_a_message_naming_the_va
 
     rec = bench.gpu_numa_affinity("cpu", pin=False)
     assert rec["pinned"] is False and "note" in rec
-    src = open(bench.__file__).read()
-    assert "HIP_VISIBLE_DEVICES" in src and "torch.cuda.device_count() > local_rank" in src
+    # all of the node's GPUs visible: cuda:LOCAL_RANK; the launcher narrowed this rank's view to its own GPU: cuda:0; anything else: a message
+    assert bench.device_index_for(5, 5, 8, env={}) == 5
+    assert bench.device_index_for(5, 5, 1, env={"HIP_VISIBLE_DEVICES": "5"}) == 0
+    assert bench.device_index_for(3, 3, 1, env={"ROCR_VISIBLE_DEVICES": "3"}) == 0
+    for n_vis, env in ((1, {}), (4, {"HIP_VISIBLE_DEVICES": "0,1,2,3"}), (0, {})):
+        with pytest.raises(AssertionError, match="HIP_VISIBLE_DEVICES"):
+            bench.device_index_for(6, 6, n_vis, env=env)
     assert bench.asked_global_batch("strong", 8, 513, 4097) == 4097 and bench.asked_global_batch("weak", 8, 4096, 0) == 32768
     assert bench.asked_global_batch("million", 8, 125000, 0) == 1_000_000
 
