@@ -518,12 +518,18 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   };
 
   ro_f4 acc[NCB];
+  // as in the row-owner launch: odd k groups accumulate into a second set (two half-length f32 chains per output) wherever a wave runs the
+  // whole k range (the k-split forms have shorter chains already)
+  constexpr bool TWO = KS == 1;
+  ro_f4 accb[TWO ? NCB : 1];
+#define RC_ACC(i_) ((TWO && ((i_) & 1)) ? accb : acc)
   ro_f4 af[2];
   // LeakyReLU of the accumulators -> own columns of the LDS tile, and (PUB) write-through to the row tile's exchange buffer
 #define RC_EPILOGUE(tile_out, PUB, rsX)                                                                                  \
   if constexpr (KS == 1) {                                                                                               \
     _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) {                                                              \
       ro_f4 v_ = acc[cb_];                                                                                               \
+      if constexpr (TWO) v_ += accb[cb_];                                                                                \
       v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
       const int col_ = (int)(cbg0 + cb_) * 16 + 4 * lq;                                                                  \
       *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + (bw + cb_) * 16 + 4 * lq) = v_;                             \
@@ -551,6 +557,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
 #define RC_LAYER(hl_, bias_, tile_in, rsXin, e_in, WAIT)                                                                 \
   {                                                                                                                      \
     _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = ks == 0 ? bias_[cb_] : ro_f4{0.f, 0.f, 0.f, 0.f};   \
+    if constexpr (TWO) { _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) accb[cb_] = ro_f4{0.f, 0.f, 0.f, 0.f}; }  \
     if (!(WAIT && WAIT_AT == 0)) af[0] = RC_AFRAG(tile_in, 0);                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < KGW; ++i_) {                                                                 \
       if (WAIT && i_ == WAIT_AT) {                                                                                       \
@@ -561,7 +568,8 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       RC_ISSUE((i_ + PF) % NBUF, (hl_) + ((i_ + PF) / KGW), (i_ + PF) % KGW)                                             \
       if (i_ + 1 < KGW && !(WAIT && i_ + 1 == WAIT_AT)) af[(i_ + 1) & 1] = RC_AFRAG(tile_in, i_ + 1);                    \
       _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)                                                                   \
-          _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_) acc[cb_] = RO_MFMA(wb[i_ % NBUF][cb_][c_], af[i_ & 1][c_], acc[cb_]); \
+          _Pragma("unroll") for (int cb_ = 0; cb_ < NCB; ++cb_)                                                          \
+              RC_ACC(i_)[cb_] = RO_MFMA(wb[i_ % NBUF][cb_][c_], af[i_ & 1][c_], RC_ACC(i_)[cb_]);                        \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                 \
       _Pragma("unroll") for (int q_ = 0; q_ < NCB; ++q_) {                                                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                               \

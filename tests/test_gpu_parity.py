@@ -91,11 +91,12 @@ def test_flow_panda_matches_oracle(n, clamp):
     assert e64 <= FLOW_TOL
 
 
-@pytest.mark.parametrize("gain,n", [(2.0, 256), (2.0, 4096), (2.5, 4096)])
+@pytest.mark.parametrize("gain,n", [(2.0, 256), (2.0, 4096), (2.5, 4096), (2.5, 100), (2.5, 256), (2.5, 512), (2.5, 1024), (2.5, 2048), (2.5, 3000)])
 def test_flow_panda_trained_like_gain(gain, n):
     """Coupling coefficients of O(1) - last-Linear outputs scaled by `gain`, so atan / exp work away from 0 and the clamp saturates:
-    every row of the batch (256 rows: the per-layer small-batch kernels; 4096: the row-owner launch), unclamped outputs, 1e-5 relative to
-    max(1, |x|) against the fp64 twin (r03 measured 1e-6 there and asserted 2e-5), and no further from it than four times the torch-CPU oracle is."""
+    every row of the batch through every form of the plan (100 / 256 / 512 / 1024 / 2048 rows: the cluster form with 32 / 16 / 8 / 4 / 2 members;
+    3000: two cluster chunks; 4096: the row-owner launch), unclamped outputs, 1e-5 relative to max(1, |x|) against the fp64 twin, and no further
+    from it than twice the torch-CPU oracle is (+ 1e-6)."""
     robot, hp, lay, sd = panda_model(seed=3, gain=gain)
     _, poses = reachable_poses(robot, n, 5)
     lat = latents(n, lay.dim, 6)
@@ -109,8 +110,9 @@ def test_flow_panda_trained_like_gain(gain, n):
     e64 = (np.abs(got.numpy() - ref64) / scale).max()
     o64 = (np.abs(ref32.numpy() - ref64) / scale).max()
     print(f"gain {gain} n={n}: rel |hip-f64|={e64:.3e} |cpu32-f64|={o64:.3e}, max |x| {np.abs(ref64).max():.1f}")
-    # (measured r04: 1.9e-6 / 2.3e-6 / 3.4e-6 for the three cases against the oracle's own 1.3e-6 / 2.2e-6 / 2.7e-6; with ONE f32 chain of 1024
-    # products per output the row-owner launch was at 3.9e-6 / 8.1e-6 - it now runs two half-length chains)
+    # (measured r04 at gain 2.5: 1.6e-6 / 2.1e-6 / 2.5e-6 / 3.7e-6 / 3.7e-6 / 3.7e-6 / 3.4e-6 for 100 ... 4096 rows against the oracle's own
+    # 1.9e-6 ... 2.7e-6; with ONE f32 chain of 1024 products per output the row-owner launch was at 8.1e-6, the 8- and 2-member cluster forms at
+    # 4.4e-6 / 5.5e-6 - every form now runs two half-length chains, or shorter ones where waves split the k range)
     assert e64 <= FLOW_TOL and e64 <= 2 * o64 + 1e-6
 
 
