@@ -495,24 +495,36 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     ro_barrier();
     return s_ok != 0;
   };
-  // the peers' column slices of an exchanged activation -> this workgroup's LDS tile
+  // the peers' column slices of an exchanged activation -> this workgroup's LDS tile (member-relative column order: peer j + m at columns
+  // [m CS, (m + 1) CS)).  One address register for the loads and one for the LDS writes; the rest is a scalar offset per load and an
+  // immediate per write (a per-load index computation is loop-invariant, gets hoisted out of the subnet loop and costs two registers per
+  // load for the whole kernel).  All loads of a thread (<= 8) are in flight together.
   auto gather = [&](const __amdgpu_buffer_rsrc_t& rsX, float* tile) {
-    constexpr int PEER4 = RO_ROWS * CS / 4;                         // float4 of one peer's slice
-    constexpr int TOTAL = (G - 1) * PEER4;
-    constexpr int NLD = (TOTAL + RO_WAVES * 64 - 1) / (RO_WAVES * 64);   // loads per thread, all in flight together (<= 8)
+    constexpr int TH = RO_WAVES * 64;
+    constexpr int PEER4 = RO_ROWS * CS / 4;                     // float4 of one peer's slice: 2048 / 1024 / 512 / 256 / 128
+    constexpr int C4 = CS / 4;
+    constexpr int PPR = PEER4 >= TH ? 1 : TH / PEER4;           // peers per round of 512 loads: 1 / 1 / 1 / 2 / 4 (by groups of waves)
+    constexpr int RPP = PEER4 >= TH ? PEER4 / TH : 1;           // rounds per peer: 4 / 2 / 1 / 1 / 1
+    constexpr int ROWS_PR = TH / PPR / C4;                      // rows a round covers: 4 / 8 / 16 / 16 / 16
+    constexpr int NLD = PPR == 1 ? (G - 1) * RPP : G / PPR;     // rounds = loads per thread: 4 / 6 / 7 / 8 / 8
+    static_assert(NLD <= 8, "all loads of a gather in flight together");
+    const int hw = PPR == 1 ? 0 : wave / (RO_WAVES / PPR);      // (wave-uniform) which of the round's peers
+    const int tt = PPR == 1 ? t : (t & (TH / PPR - 1));
+    const int row_t = tt / C4, c4 = tt % C4;
+    const unsigned voffx = (unsigned)((row_t * RO_W + c4 * 4) * 4);
+    float* const tdst = tile + row_t * RO_LDA + c4 * 4 + hw * (NLD * CS);
     ro_f4 v[NLD];
 #pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      const int idx = t + q * (RO_WAVES * 64);
-      const int m = 1 + idx / PEER4, w4 = idx % PEER4, row = w4 / (CS / 4), c4 = w4 % (CS / 4);
-      const int p = (j + m) % G;
-      if (idx < TOTAL) v[q] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (unsigned)((row * RO_W + p * CS + c4 * 4) * 4), 0, /*sc1*/ 16));
+    for (int r = 0; r < NLD; ++r) {
+      const int mq = 1 + r / RPP, rr = r % RPP;                  // (compile-time) peer of the round's first wave group, row group
+      const int m = mq + hw * NLD;
+      const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((rr * ROWS_PR * RO_W + ((j + m) & (G - 1)) * CS) * 4);
+      if (m < G) v[r] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voffx, so, /*sc1*/ 16));
     }
 #pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-      const int idx = t + q * (RO_WAVES * 64);
-      const int m = 1 + idx / PEER4, w4 = idx % PEER4, row = w4 / (CS / 4), c4 = w4 % (CS / 4);
-      if (idx < TOTAL) *reinterpret_cast<ro_f4*>(tile + row * RO_LDA + m * CS + c4 * 4) = v[q];   // member-relative column order
+    for (int r = 0; r < NLD; ++r) {
+      const int mq = 1 + r / RPP, rr = r % RPP;
+      if (mq + hw * NLD < G) *reinterpret_cast<ro_f4*>(tdst + rr * ROWS_PR * RO_LDA + mq * CS) = v[r];
     }
     ro_barrier();
   };
