@@ -1139,13 +1139,16 @@ struct TailPlan {
   double cost;
   std::vector<FlowChunk> chunks;
 };
-static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool cl, std::unordered_map<long long, TailPlan>& memo) {
+// (mixed: the chunk is not the whole call.  The per-layer kernels read their own weight images (2 x 203 MB with the row-owner stream): next to
+// a chunk of another form they find the Infinity Cache holding the other image and leave it holding theirs for the next call - measured + 0.07
+// ... 0.1 ms on a 513- / 1025- / 2049-row call whose last row went to them; the resident-row forms share one image.)
+static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool cl, bool mixed, std::unordered_map<long long, TailPlan>& memo) {
   auto it = memo.find(rows);
   if (it != memo.end()) return it->second;
   TailPlan best{0.0, {}};
   if (rows > 0) {
     const long long on256 = rows * 4096 / round;   // the cost tables are in rows of a 256-CU chip
-    best = TailPlan{per_layer_cost(on256), {{0, rows}}};
+    best = TailPlan{per_layer_cost(on256) + (mixed ? 0.10 : 0.0), {{0, rows}}};
     if (ro && 2.82 < best.cost) best = TailPlan{2.82, {{1, rows}}};
     if (cl) {
       static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
@@ -1155,7 +1158,7 @@ static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool 
         if (rows <= cap) {                   // the whole tail in one launch of this form
           if (f.ms < best.cost) best = TailPlan{f.ms, {{f.G, rows}}};
         } else if (f.G <= 8) {               // a full launch of this form, then the plan of what is left
-          const TailPlan rest = plan_tail(rows - cap, round, ro, cl, memo);   // (by value: the map may rehash)
+          const TailPlan rest = plan_tail(rows - cap, round, ro, cl, true, memo);   // (by value: the map may rehash)
           const double c = f.ms + 0.01 + rest.cost;
           if (c < best.cost) {
             best = TailPlan{c, {{f.G, cap}}};
@@ -1185,7 +1188,7 @@ static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
       else tail = {{0, rows - full}};
     } else {
       std::unordered_map<long long, TailPlan> memo;
-      tail = plan_tail(rows - full, round, ro, cl, memo).chunks;
+      tail = plan_tail(rows - full, round, ro, cl, full > 0, memo).chunks;
     }
   }
   if (full > 0) plan.push_back({1, full});

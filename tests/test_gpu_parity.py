@@ -1588,7 +1588,9 @@ def test_plan_of_a_call_by_batch_size():
             512: "cluster8:512", 600: "cluster8:512 cluster32:88", 1024: "cluster4:1024", 1536: "cluster8:512 cluster4:1024", 2048: "cluster2:2048",
             2560: "cluster8:512 cluster2:2048", 3072: "cluster4:1024 cluster2:2048", 3400: "rowowner:3400", 4096: "rowowner:4096",
             4096 + 200: "rowowner:4096 cluster16:200", 8192: "rowowner:8192", 3 * 4096 + 3500: "rowowner:15788",
-            1_000_000 // 8: "rowowner:122880 cluster2:2048 cluster32:72"}
+            1_000_000 // 8: "rowowner:122880 cluster2:2048 cluster32:72",
+            # a last row next to another form stays on the resident-row forms (one weight image in the Infinity Cache, not two)
+            513: "cluster8:512 cluster32:1", 1025: "cluster4:1024 cluster32:1", 2049: "cluster2:2048 cluster32:1", 4097: "rowowner:4096 cluster32:1"}
     import time
 
     t0 = time.perf_counter()
