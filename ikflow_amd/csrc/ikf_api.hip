@@ -1103,9 +1103,9 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
 // consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
 // tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
 //   row-owner round 2.82;  cluster 0.285 / 0.38 / 0.53 / 0.86 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
-//   per-layer 0.272 / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
+//   per-layer 0.29 (measured 0.273: see per_layer_cost) / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
 //   2048 / 2560 / 3072 / 4096 rows;  + 0.01 per extra chunk (its launches' boundaries).
-// e.g. 1 -> per-layer; 16 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
+// e.g. 1 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
 // 3400 -> one row-owner round; 4096 k + r -> k rounds in one row-owner launch + the plan of r.
 struct FlowChunk {
   int form;         // 0 per-layer, 1 row-owner, 2 / 4 / 8 cluster members
@@ -1126,7 +1126,10 @@ static bool cluster_allowed(ikf_model* m) {
   return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
 }
 static double per_layer_cost(long long rows_on_256) {
-  static const struct { long long rows; double ms; } t[] = {{1, 0.272}, {16, 0.305}, {64, 0.316}, {128, 0.367}, {256, 0.52}, {512, 0.71}, {1024, 1.04},
+  // (1 row alone measures 0.273 against 0.277 for cluster32:1 - charged 0.29 so that, where the resident-row forms are allowed, EVERY size
+  // uses the same weight image: a caller that alternates 1-row and larger calls, or an exact-IK call on one pose (rounds of 1, 3, 10 rows),
+  // would otherwise swap two 203 MB images through the 256 MB Infinity Cache)
+  static const struct { long long rows; double ms; } t[] = {{1, 0.29}, {16, 0.305}, {64, 0.316}, {128, 0.367}, {256, 0.52}, {512, 0.71}, {1024, 1.04},
                                                             {2048, 1.75}, {2560, 2.56}, {3072, 2.62}, {4096, 3.20}};
   for (const auto& e : t)
     if (rows_on_256 <= e.rows) return e.ms;

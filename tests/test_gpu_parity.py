@@ -1087,7 +1087,7 @@ def test_resident_row_forms_random_configurations(cfg):
     err = ((got - ref).abs() / scale).max().item()
     err64 = ((got - ref64).abs() / scale).max().item()
     plan = eng.plan(n)
-    assert plan != f"perlayer:{n}" or n < 8, plan   # (these shapes are the resident-row forms' domain)
+    assert plan != f"perlayer:{n}", plan   # (these shapes are the resident-row forms' domain)
     assert err <= FLOW_TOL or err64 <= 4 * cpu_noise, f"{cfg} n={n} plan {plan}: {err:.2e} vs fp32, {err64:.2e} vs fp64 (cpu {cpu_noise:.2e})"
 
 
@@ -1529,7 +1529,7 @@ def test_cluster_form_default_split_and_many_calls_in_flight():
     _, poses = reachable_poses(robot, n, 17)
     lat = latents(n, lay.dim, 18)
     P, L = poses.to(DEV), lat.to(DEV)
-    assert "cluster" in eng.dominant_kernel_name(512) and "rowowner" in eng.dominant_kernel_name(n) and "gemm" in eng.dominant_kernel_name(1)
+    assert "cluster" in eng.dominant_kernel_name(512) and "rowowner" in eng.dominant_kernel_name(n) and "cluster" in eng.dominant_kernel_name(1)
     assert "cluster" in eng.dominant_kernel_name(128) and "cluster" in eng.dominant_kernel_name(16)
     eng.profile_begin()
     full = s.generate_ik_solutions(P, latent=L)
@@ -1584,7 +1584,7 @@ def test_plan_of_a_call_by_batch_size():
     robot, hp, lay, sd = panda_model()
     s = _solver(robot, hp, sd)
     eng = s.engine(DEV)
-    want = {1: "perlayer:1", 8: "cluster32:8", 16: "cluster32:16", 128: "cluster32:128", 200: "cluster16:200", 256: "cluster16:256", 300: "cluster8:300",
+    want = {1: "cluster32:1", 8: "cluster32:8", 16: "cluster32:16", 128: "cluster32:128", 200: "cluster16:200", 256: "cluster16:256", 300: "cluster8:300",
             512: "cluster8:512", 600: "cluster8:512 cluster32:88", 1024: "cluster4:1024", 1536: "cluster8:512 cluster4:1024", 2048: "cluster2:2048",
             2560: "cluster8:512 cluster2:2048", 3072: "cluster4:1024 cluster2:2048", 3400: "rowowner:3400", 4096: "rowowner:4096",
             4096 + 200: "rowowner:4096 cluster16:200", 8192: "rowowner:8192", 3 * 4096 + 3500: "rowowner:15788",
@@ -1640,7 +1640,7 @@ def test_row_owner_form_is_what_the_baseline_batch_runs():
     s.generate_ik_solutions(P[:4096], latent=L[:4096])
     n_launch, _ = eng.profile_end()
     assert n_launch == 1, "4096 rows = one row-owner launch"
-    assert "rowowner" in eng.dominant_kernel_name(4096) and "gemm" in eng.dominant_kernel_name(1)
+    assert "rowowner" in eng.dominant_kernel_name(4096) and "cluster" in eng.dominant_kernel_name(1)   # (one weight image for every size)
 
 
 @pytest.mark.parametrize("kw", [
