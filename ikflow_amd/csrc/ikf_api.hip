@@ -1103,8 +1103,8 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
 // consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
 // tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
 //   row-owner round 2.82;  cluster 0.285 / 0.38 / 0.53 / 0.86 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
-//   per-layer 0.29 (measured 0.273: see per_layer_cost) / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
-//   2048 / 2560 / 3072 / 4096 rows;  + 0.01 per extra chunk (its launches' boundaries).
+//   per-layer 0.272 / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
+//   2048 / 2560 / 3072 / 4096 rows (+ 0.10 beside the resident-row forms: another weight image, see plan_tail);  + 0.01 per extra chunk.
 // e.g. 1 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
 // 3400 -> one row-owner round; 4096 k + r -> k rounds in one row-owner launch + the plan of r.
 struct FlowChunk {
@@ -1126,10 +1126,7 @@ static bool cluster_allowed(ikf_model* m) {
   return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
 }
 static double per_layer_cost(long long rows_on_256) {
-  // (1 row alone measures 0.273 against 0.277 for cluster32:1 - charged 0.29 so that, where the resident-row forms are allowed, EVERY size
-  // uses the same weight image: a caller that alternates 1-row and larger calls, or an exact-IK call on one pose (rounds of 1, 3, 10 rows),
-  // would otherwise swap two 203 MB images through the 256 MB Infinity Cache)
-  static const struct { long long rows; double ms; } t[] = {{1, 0.29}, {16, 0.305}, {64, 0.316}, {128, 0.367}, {256, 0.52}, {512, 0.71}, {1024, 1.04},
+  static const struct { long long rows; double ms; } t[] = {{1, 0.272}, {16, 0.305}, {64, 0.316}, {128, 0.367}, {256, 0.52}, {512, 0.71}, {1024, 1.04},
                                                             {2048, 1.75}, {2560, 2.56}, {3072, 2.62}, {4096, 3.20}};
   for (const auto& e : t)
     if (rows_on_256 <= e.rows) return e.ms;
@@ -1142,16 +1139,18 @@ struct TailPlan {
   double cost;
   std::vector<FlowChunk> chunks;
 };
-// (mixed: the chunk is not the whole call.  The per-layer kernels read their own weight images (2 x 203 MB with the row-owner stream): next to
-// a chunk of another form they find the Infinity Cache holding the other image and leave it holding theirs for the next call - measured + 0.07
-// ... 0.1 ms on a 513- / 1025- / 2049-row call whose last row went to them; the resident-row forms share one image.)
+// The per-layer kernels read their own weight images (2 x 203 MB beside the row-owner stream's 203 MB; the Infinity Cache holds 256 MB): next
+// to a chunk of another form (mixed), or on a handle whose other calls use the cluster form (cl), they find the cache holding the other
+// image and leave it holding theirs - measured + 0.07 ... 0.1 ms on a 513- / 1025- / 2049-row call whose last row went to them.  They are
+// charged for it, so that where the resident-row forms are allowed EVERY size reads one image (1 row alone: 0.273 against cluster32's 0.277;
+// an exact-IK call on one pose runs rounds of 1, 3, 10 rows); they remain what a handle without those forms, or another shape, runs.
 static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool cl, bool mixed, std::unordered_map<long long, TailPlan>& memo) {
   auto it = memo.find(rows);
   if (it != memo.end()) return it->second;
   TailPlan best{0.0, {}};
   if (rows > 0) {
     const long long on256 = rows * 4096 / round;   // the cost tables are in rows of a 256-CU chip
-    best = TailPlan{per_layer_cost(on256) + (mixed ? 0.10 : 0.0), {{0, rows}}};
+    best = TailPlan{per_layer_cost(on256) + ((mixed || cl) ? 0.10 : 0.0), {{0, rows}}};
     if (ro && 2.82 < best.cost) best = TailPlan{2.82, {{1, rows}}};
     if (cl) {
       static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
@@ -1173,21 +1172,22 @@ static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool 
   }
   return memo.emplace(rows, std::move(best)).first->second;
 }
-static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
+// (host logic only - no device, no handle: ikf_plan_describe_for runs it in the CPU tests.  ro / cl: the form may be used at all;
+// ro_mode / cl_mode 1: forced; ro_min_tail >= 0: the probes' explicit threshold for the last partial round)
+static std::vector<FlowChunk> plan_rows(long long rows, int n_cu, bool ro, bool cl, int ro_mode, int cl_mode, long long ro_min_tail) {
   std::vector<FlowChunk> plan;
-  if (rows <= 0) return plan;
-  const bool ro = rowowner_allowed(m), cl = cluster_allowed(m);
-  const long long round = (long long)m->n_cu * IKF_RO_ROWS;
-  if (ro && m->ro_mode == 1) return {{1, rows}};
-  if (cl && m->cl_mode == 1 && rows <= round / 2) {  // forced: one launch of the widest form whose grid fits
+  if (rows <= 0 || n_cu <= 0) return plan;
+  const long long round = (long long)n_cu * IKF_RO_ROWS;
+  if (ro && ro_mode == 1) return {{1, rows}};
+  if (cl && cl_mode == 1 && rows <= round / 2) {  // forced: one launch of the widest form whose grid fits
     for (int g = 32; g >= 2; g /= 2)
-      if (rows <= (long long)(m->n_cu / g) * IKF_RO_ROWS) return {{g, rows}};
+      if (rows <= (long long)(n_cu / g) * IKF_RO_ROWS) return {{g, rows}};
   }
   const long long full = ro ? rows / round * round : 0;
   std::vector<FlowChunk> tail;
   if (rows - full > 0) {
-    if (ro && m->ro_min_tail >= 0) {  // (probes: an explicit threshold for the last partial round)
-      if (rows - full >= m->ro_min_tail) tail = {{1, rows - full}};
+    if (ro && ro_min_tail >= 0) {
+      if (rows - full >= ro_min_tail) tail = {{1, rows - full}};
       else tail = {{0, rows - full}};
     } else {
       std::unordered_map<long long, TailPlan> memo;
@@ -1200,6 +1200,19 @@ static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
     else plan.push_back(c);
   }
   return plan;
+}
+static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
+  if (rows <= 0) return {};
+  const bool ro = rowowner_allowed(m), cl = cluster_allowed(m);
+  return plan_rows(rows, m->n_cu, ro, cl, m->ro_mode, m->cl_mode, m->ro_min_tail);
+}
+static std::string plan_text(const std::vector<FlowChunk>& plan) {
+  std::string out;
+  for (const FlowChunk& c : plan) {
+    if (!out.empty()) out += " ";
+    out += (c.form == 0 ? std::string("perlayer") : c.form == 1 ? std::string("rowowner") : "cluster" + std::to_string(c.form)) + ":" + std::to_string(c.rows);
+  }
+  return out;
 }
 static RoArgs rowowner_args(ikf_model* m, const PoseSource& ps, const float* d_latent, long long r0, long long nr, int clamp_limits, float* d_q_out) {
   const FlowDims& d = m->dims;
@@ -1265,12 +1278,17 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
 // "rowowner:4096 cluster16:200" - the chunks run_flow would cut a call of `rows` rows into (tests / tools)
 extern "C" ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len) {
   if (!m || !buf || buf_len < 1) return fail(IKF_ERR_NULL_POINTER, "ikf_plan_describe: null argument");
-  std::string out;
-  for (const FlowChunk& c : plan_flow(m, rows)) {
-    if (!out.empty()) out += " ";
-    out += (c.form == 0 ? std::string("perlayer") : c.form == 1 ? std::string("rowowner") : "cluster" + std::to_string(c.form)) + ":" + std::to_string(c.rows);
-  }
+  const std::string out = plan_text(plan_flow(m, rows));
   if ((int)out.size() + 1 > buf_len) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_plan_describe: buffer too small");
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return IKF_OK;
+}
+// the same decision without a handle or a device: a chip of n_cu CUs, the resident-row forms allowed or not (released shape, f32)
+extern "C" ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, int cluster_allowed, char* buf, int buf_len) {
+  if (!buf || buf_len < 1) return fail(IKF_ERR_NULL_POINTER, "ikf_plan_describe_for: null argument");
+  if (n_cu <= 0) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_plan_describe_for: n_cu must be positive");
+  const std::string out = plan_text(plan_rows(rows, n_cu, rowowner_allowed != 0, cluster_allowed != 0, -1, -1, -1));
+  if ((int)out.size() + 1 > buf_len) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_plan_describe_for: buffer too small");
   memcpy(buf, out.c_str(), out.size() + 1);
   return IKF_OK;
 }

@@ -37,6 +37,9 @@ const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
 /* The chunks a call of `rows` rows is cut into on this handle with its current settings, e.g. "rowowner:4096 cluster16:200"
  * (forms: perlayer, rowowner, cluster<G>). */
 ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len);
+/* The same decision as pure host logic - no handle, no device: a chip of n_cu CUs, the released shape in f32, the row-owner launch and
+ * the cluster form allowed (1) or not (0).  (CPU tests of the planner.) */
+ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, int cluster_allowed, char* buf, int buf_len);
 /* Select the flow pipeline (a tuning / test switch; every setting computes the same function):
  *   -1 auto (3-kernel-per-subnet fused form when the shape allows), 100 the same explicitly, 101..108 the fused form with tile
  *   configuration 0..7 forced, 160 with the 16 x 32 small-batch tiles forced; 0..8 the unfused 4-kernel form with that tile variant;

@@ -340,3 +340,48 @@ def test_approximate_panda_capsule_model_host_side():
     assert all(abs(folded[a][0] - folded[b][0]) > 1 for a, b in pairs) and len(pairs) == 45
     with pytest.raises(ValueError, match="only for 'panda'"):
         FetchArm().use_approximate_collision_model()
+
+
+def _plan_for(lib, n_cu, rows, ro=1, cl=1):
+    buf = ctypes.create_string_buffer(1024)
+    assert lib.ikf_plan_describe_for(n_cu, rows, ro, cl, buf, 1024) == 0
+    return buf.value.decode()
+
+
+def test_planner_decisions_and_invariants_host_side():
+    """plan_flow is host logic: through the handle-free entry point the CPU suite checks what the GPU test
+    `test_plan_of_a_call_by_batch_size` checks on a live handle - the decisions of section 4.0's table on a 256-CU chip - and, over every row
+    count up to three rounds on several chip sizes, what must hold whatever the cost tables say: the chunks add up to the call, every
+    cluster chunk's grid (row tiles x members) fits the chip with one workgroup per CU, no chunk is empty, and - on the 256-CU chip the costs
+    were measured on - nothing goes to the per-layer kernels where the resident-row forms are allowed (one weight image for every size)."""
+    import time
+
+    lib = _lib.load()
+    want = {1: "cluster32:1", 8: "cluster32:8", 128: "cluster32:128", 129: "cluster16:129", 256: "cluster16:256", 257: "cluster8:257",
+            512: "cluster8:512", 513: "cluster8:512 cluster32:1", 600: "cluster8:512 cluster32:88", 1024: "cluster4:1024",
+            1025: "cluster4:1024 cluster32:1", 1536: "cluster8:512 cluster4:1024", 2048: "cluster2:2048", 2049: "cluster2:2048 cluster32:1",
+            2560: "cluster8:512 cluster2:2048", 3072: "cluster4:1024 cluster2:2048", 3400: "rowowner:3400", 4096: "rowowner:4096",
+            4097: "rowowner:4096 cluster32:1", 4296: "rowowner:4096 cluster16:200", 8192: "rowowner:8192", 15788: "rowowner:15788",
+            125000: "rowowner:122880 cluster2:2048 cluster32:72"}
+    got = {n: _plan_for(lib, 256, n) for n in want}
+    assert got == want, {n: (got[n], want[n]) for n in want if got[n] != want[n]}
+    assert _plan_for(lib, 256, 0) == "" and _plan_for(lib, 256, 300, 0, 0) == "perlayer:300"
+    assert _plan_for(lib, 256, 4096, 1, 0) == "rowowner:4096" and _plan_for(lib, 256, 4096, 0, 1) == "cluster2:2048 cluster2:2048"
+    assert _plan_for(lib, 256, 200, 1, 0) == "perlayer:200"   # (a short call without the cluster form: not worth a row-owner round)
+    buf = ctypes.create_string_buffer(8)
+    assert lib.ikf_plan_describe_for(256, 125000, 1, 1, buf, 8) != 0 and lib.ikf_plan_describe_for(0, 10, 1, 1, buf, 8) != 0
+    t0 = time.perf_counter()
+    checked = 0
+    for n_cu in (256, 240, 304, 64, 8):
+        round_rows = 16 * n_cu
+        for rows in list(range(1, 3 * round_rows + 40, 7 if n_cu > 64 else 1)) + [round_rows - 1, round_rows, round_rows + 1, 10 * round_rows + 5]:
+            chunks = [c.split(":") for c in _plan_for(lib, n_cu, rows).split()]
+            assert sum(int(r) for _, r in chunks) == rows and all(int(r) > 0 for _, r in chunks), (n_cu, rows, chunks)
+            for form, r in chunks:
+                assert form != "perlayer" or n_cu != 256, (n_cu, rows, chunks)   # (the chip the costs were measured on: one weight image for every size)
+                if form.startswith("cluster"):
+                    g = int(form[len("cluster"):])
+                    assert g in (2, 4, 8, 16, 32) and (int(r) + 15) // 16 * g <= n_cu, (n_cu, rows, chunks)
+            assert sum(1 for f, _ in chunks if f == "rowowner") <= 1 and (chunks[0][0] == "rowowner" or rows < round_rows), (n_cu, rows, chunks)
+            checked += 1
+    assert (time.perf_counter() - t0) / checked < 1e-3   # planned on the host in front of every call
