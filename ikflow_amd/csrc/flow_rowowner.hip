@@ -18,7 +18,8 @@
 //   * rows are independent: no inter-workgroup synchronisation, no activation ever goes to HBM, no entry / finalize launches.
 // The price is the weight stream: every CU reads every weight (32 B/clk/CU from its XCD's L2 while the matrix pipe runs flat out).
 // Numerics: exact f32 fma chains on the matrix pipe like the per-layer kernels; another summation order (k ascending inside 16-k
-// groups permuted as k = 16 g + 4 j + c -> (c, j)), same tolerance against the oracle.
+// groups permuted as k = 16 g + 4 j + c -> (c, j); even and odd groups in two chains that are added at the end), same tolerance
+// against the oracle.
 #include "ikf_internal.h"
 
 namespace ikf {
