@@ -25,7 +25,6 @@ import numpy as np
 import torch
 
 from ikflow_amd import config
-from ikflow_amd.config import DEFAULT_TORCH_DTYPE
 from ikflow_amd.model import (
     IkflowModelParameters,
     layout_from,

@@ -15,7 +15,7 @@ state_dict key names) that the engine packs once into its HBM layo
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Tuple
 
 import numpy as np
 

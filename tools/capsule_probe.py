@@ -18,7 +18,6 @@ q = torch.tensor(r.sample_joint_angles(20000, 0.0, np.random.default_rng(0)), de
 d = r.self_collision_distances(q)
 print("random configs colliding fraction", float((d < 0).float().mean()), "min", float(d.min()))
 # which pairs collide most
-import itertools
 from ikflow_amd.engine import kinematics_engine_for
 eng = kinematics_engine_for(r, "cuda")
 for (a,b) in pairs:

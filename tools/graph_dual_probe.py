@@ -1,7 +1,7 @@
 """Experiment: hipGraph with S parallel branches, each the launch chain of one sub-batch (host launch cost out of the way)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from ikflow_amd.ikflow_solver import IKFlowSolver
 from ikflow_amd.model import hparams_for, layout_from, random_state_dict
 from ikflow_amd.robots import Panda

@@ -4,8 +4,7 @@ Captures Engine.generate_approx on a side stream with torch.cuda.CUDAGraph (the 
 caller's stream once scratch is reserved) and times direct launches against graph replays."""
 import sys, time
 import torch
-from ikflow_amd.engine import Engine
-from ikflow_amd.model import FlowLayout, random_state_dict
+from ikflow_amd.model import random_state_dict
 from ikflow_amd.robots import get_robot
 
 from ikflow_amd.ikflow_solver import IKFlowSolver

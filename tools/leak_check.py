@@ -1,6 +1,6 @@
 import torch, gc
 from ikflow_amd.ikflow_solver import IKFlowSolver
-from ikflow_amd.model import MODEL_DESCRIPTIONS, hparams_for, layout_from, random_state_dict
+from ikflow_amd.model import hparams_for, layout_from, random_state_dict
 from ikflow_amd.robots import get_robot
 name="panda__full__lp191_5.25m"
 robot=get_robot("panda"); hp=hparams_for(name); lay=layout_from(hp,robot); sd=random_state_dict(lay,robot,0)

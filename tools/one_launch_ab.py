@@ -1,6 +1,6 @@
 import sys, os, time
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+import torch
 from ikflow_amd.ikflow_solver import IKFlowSolver
 from ikflow_amd.model import hparams_for, layout_from, random_state_dict
 from ikflow_amd.robots import Panda
