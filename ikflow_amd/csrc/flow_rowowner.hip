@@ -320,7 +320,20 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr unsigned kClusterSpinLimit = 1u << 18;   // polls of (s_sleep 1 + one L2-missing load): some 0.1 s - a peer that is not resident
 
-template <int G>
+__device__ __forceinline__ void ro_give_up_once(int* give_up) {   // 0 -> 1; a 2 (placement) already there stays
+  int expected = 0;
+  (void)__hip_atomic_compare_exchange_strong(give_up, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID
+
+// LOCAL (G = 8 / 16): every member of a row tile on ONE XCD - workgroup b is member (b / 8) % G of tile b % 8 + 8 ((b / 8) / G); with the
+// observed placement b -> XCD b % 8 the tile lives on XCD b % 8 - and the hand-over goes through that XCD's L2: plain stores (they stay in
+// the L2 every member shares; the drain waits for the L2, not for memory), same epoch words, same sc1 loads (L1-bypassing).  3.4 % / 4.5 %
+// off a 512- / 256-row call; every L2 then pulls every member's weight slice (8 x the fabric traffic) - which is why G = 32 stays spread
+// (0.34 against 0.28 ms at 128 rows) and G = 4 / 2 gain nothing (1.5 % / 0).  NOTHING is assumed: a member publishes its XCC_ID in the top
+// byte of every epoch word, a consumer that meets another XCD's id gives up (abort word, host word = 2) BEFORE it reads a payload, the
+// repair launch recomputes the rows, and the handle goes back to the spread form.
+template <int G, bool LOCAL>
 __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   constexpr int NBM = RO_KG / G;                     // 16-column blocks of one member's slice (= 16-k groups of its k range)
   constexpr int KS = NBM >= RO_WAVES ? 1 : RO_WAVES / NBM;   // G >= 16: fewer blocks than waves - KS waves split the k range of a block
@@ -344,7 +357,12 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   __shared__ float s_sum[RO_ROWS * RO_RS];   // the pending subnet's summed last-Linear outputs (bias included)
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int j = blockIdx.x % G, rt = blockIdx.x / G;
+  const int j = LOCAL ? (int)(blockIdx.x / 8) % G : (int)blockIdx.x % G;
+  const int rt = LOCAL ? (int)(blockIdx.x % 8) + 8 * ((int)(blockIdx.x / 8) / G) : (int)blockIdx.x / G;
+  if (LOCAL && rt >= c.n_rt) return;   // (the grid is padded to whole groups of 8 row tiles; uniform per workgroup, nobody waits for these)
+  constexpr int ST_AUX = LOCAL ? 0 : 16;   // payload stores: write-back into the shared L2 / write-through (sc1)
+  const unsigned my_xcc = LOCAL ? ro_xcc_id() : 0u;
+  const unsigned pub_xcc = my_xcc ^ ((LOCAL && c.test_far != 0 && blockIdx.x == 0) ? 1u : 0u);   // (tests: workgroup 0 claims to sit elsewhere)
   if (t == 0) s_ok = 1;
   const int m0 = rt * RO_ROWS;
   const int lrow = lane & 15, lq = lane >> 4;
@@ -468,27 +486,31 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   {                                                                                                        \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                       \
     ro_barrier();                                                                                          \
-    if (t == 0) __hip_atomic_store(flags + j * 32, (unsigned)(e_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    if (t == 0) __hip_atomic_store(flags + j * 32, (unsigned)(e_) | (pub_xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
   }
-  // every peer has published epoch e_ (one wave polls, lane p watches member p); false = a wait ran out / somebody aborted
+  // every peer has published epoch e_ (one wave polls, lane p watches member p); false = a wait ran out / somebody aborted / (LOCAL) a
+  // peer sits on another XCD - found before any of its payload is read
   auto wait_peers = [&](unsigned e) -> bool {
     if (wave == 0) {
-      unsigned ok = 1;
+      unsigned ok = 1, far = 0;
       if (lane < G && lane != j) {
-        unsigned n = 0;
-        while (__hip_atomic_load(flags + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < e) {
+        unsigned n = 0, w;
+        while (((w = __hip_atomic_load(flags + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < e) {
           __builtin_amdgcn_s_sleep(1);
           if ((++n & 63u) == 0 && (n > kClusterSpinLimit || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             ok = 0;
             break;
           }
         }
+        if (LOCAL && ok && (w >> 24) != my_xcc) far = 1;
       }
-      ok = __all(ok != 0) ? 1u : 0u;
+      far = __any(far != 0) ? 1u : 0u;
+      ok = (__all(ok != 0) && !far) ? 1u : 0u;
       if (lane == 0) {
         if (!ok) {
           __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (far) __hip_atomic_store(c.give_up, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: placement, not a lost peer)
+          else ro_give_up_once(c.give_up);
         }
         s_ok = ok;
       }
@@ -546,7 +568,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
       const int col_ = (int)(cbg0 + cb_) * 16 + 4 * lq;                                                                  \
       *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + (bw + cb_) * 16 + 4 * lq) = v_;                             \
-      if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((lrow * RO_W + col_) * 4), 0, /*sc1*/ 16); \
+      if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((lrow * RO_W + col_) * 4), 0, ST_AUX); \
     }                                                                                                                    \
   } else {  /* the KS waves of a block hold partial sums over their k shares: through LDS, summed in share order */       \
     *reinterpret_cast<ro_f4*>(red + wave * (RO_ROWS * RO_RS) + lrow * RO_RS + 4 * lq) = acc[0];                          \
@@ -558,7 +580,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
           v_ += *reinterpret_cast<const ro_f4*>(red + (k_ * NBM + b_) * (RO_ROWS * RO_RS) + r_ * RO_RS + 4 * q_);        \
       v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
       *reinterpret_cast<ro_f4*>((tile_out) + r_ * RO_LDA + b_ * 16 + 4 * q_) = v_;                                       \
-      if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((r_ * RO_W + (j * NBM + b_) * 16 + 4 * q_) * 4), 0, /*sc1*/ 16); \
+      if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((r_ * RO_W + (j * NBM + b_) * 16 + 4 * q_) * 4), 0, ST_AUX); \
     }                                                                                                                    \
   }
   // (the LDS tiles hold the columns in MEMBER-RELATIVE order - own slice first, then members j+1, j+2, .. - so the rotated k order is the
@@ -653,7 +675,8 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
         const int row = t >> 4, o = t & 15;
 #pragma unroll
         for (int w = 0; w < RO_WAVES; ++w) mine += red[w * (RO_ROWS * RO_RS) + row * RO_RS + o];
-        __hip_atomic_store(P + j * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (LOCAL) P[j * 256 + t] = mine;
+        else __hip_atomic_store(P + j * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       RC_PUBLISH(2 * e0 + 2)
       RC_FIRST_STATIC   // the next subnet's first Linear, state-independent half, under the exchange's latency (w1 = its weights by now)
@@ -774,35 +797,29 @@ hipError_t launch_flow_rowowner(const RoArgs& a, int nbuf, hipStream_t s) {
 
 size_t cluster_xbuf_floats(int n_rt) { return (size_t)n_rt * RO_ROWS * RO_W; }
 size_t cluster_sync_bytes(int n_rt, int G) { return (size_t)n_rt * G * (256 * 4 + 32 * 4) + 128; }   // partial sums, epoch words, abort word
-hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups) {
-  static bool done2[64] = {}, done4[64] = {}, done8[64] = {}, done16[64] = {}, done32[64] = {};
-  // (drop_workgroups > 0: tests of the repair path - the last workgroups are not launched, their row tile's members wait in vain)
-  const unsigned grid = (unsigned)c.n_rt * (unsigned)G - (unsigned)(drop_workgroups > 0 ? 1 : 0);
-  // epochs and granule tags count from 1 inside a call: everything polled is zeroed in front of it (one memset: pbuf and flags are one block)
+template <int G, bool LOCAL>
+static hipError_t launch_cluster_g(const RcArgs& c, unsigned grid, hipStream_t s) {
+  static bool done[64] = {};
+  hipError_t e = ensure_dynamic_lds(k_flow_cluster<G, LOCAL>, RO_LDS_BYTES, done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_flow_cluster<G, LOCAL>), dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  return hipGetLastError();
+}
+bool cluster_local_form(int G) { return G == 8 || G == 16; }
+unsigned cluster_grid(int n_rt, int G, bool local) { return local ? (unsigned)((n_rt + 7) / 8 * 8 * G) : (unsigned)n_rt * (unsigned)G; }
+hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups, bool local) {
+  // (drop_workgroups > 0: tests of the repair path - the last workgroup of the spread form is not launched, its row tile's members wait in vain)
+  local = local && cluster_local_form(G) && drop_workgroups <= 0;
+  const unsigned grid = cluster_grid(c.n_rt, G, local) - (unsigned)(drop_workgroups > 0 ? 1 : 0);
+  // epochs count from 1 inside a call: everything polled is zeroed in front of it (one memset: pbuf and flags are one block)
   hipError_t e = hipMemsetAsync(c.pbuf, 0, cluster_sync_bytes(c.n_rt, G), s);
   if (e != hipSuccess) return e;
-  if (G == 2) {
-    e = ensure_dynamic_lds(k_flow_cluster<2>, RO_LDS_BYTES, done2);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_flow_cluster<2>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
-  } else if (G == 4) {
-    e = ensure_dynamic_lds(k_flow_cluster<4>, RO_LDS_BYTES, done4);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_flow_cluster<4>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
-  } else if (G == 8) {
-    e = ensure_dynamic_lds(k_flow_cluster<8>, RO_LDS_BYTES, done8);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_flow_cluster<8>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
-  } else if (G == 16) {
-    e = ensure_dynamic_lds(k_flow_cluster<16>, RO_LDS_BYTES, done16);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_flow_cluster<16>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
-  } else if (G == 32) {
-    e = ensure_dynamic_lds(k_flow_cluster<32>, RO_LDS_BYTES, done32);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_flow_cluster<32>, dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
-  } else return hipErrorInvalidValue;
-  return hipGetLastError();
+  if (G == 2) return launch_cluster_g<2, false>(c, grid, s);
+  if (G == 4) return launch_cluster_g<4, false>(c, grid, s);
+  if (G == 8) return local ? launch_cluster_g<8, true>(c, grid, s) : launch_cluster_g<8, false>(c, grid, s);
+  if (G == 16) return local ? launch_cluster_g<16, true>(c, grid, s) : launch_cluster_g<16, false>(c, grid, s);
+  if (G == 32) return launch_cluster_g<32, false>(c, grid, s);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace ikf

@@ -110,6 +110,9 @@ struct ikf_model {
   int* h_cl_give_up = nullptr;    // pinned, device-visible
   int cl_drop_next = 0;           // tests: the next cluster launch runs one workgroup short (ikf_set_gemm_variant 188): its tile's waits run out
   long long cl_repairs = 0;       // give-ups seen so far (ikf_cluster_repairs)
+  int cl_far_next = 0;            // tests (ikf_set_gemm_variant 191): the next XCD-local launch's workgroup 0 publishes a wrong XCC_ID
+  int cl_local = 1;               // G = 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
+                                  // peer on another XCD (placement is verified in the launch, never assumed) or by ikf_set_gemm_variant 189
 
   // packed weights (one arena)
   float* arena = nullptr;
@@ -739,6 +742,14 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->wt_stores = variant == 134 ? -1 : variant - 130;
     return IKF_OK;
   }
+  if (variant == 191) {  // tests of the placement check: the next XCD-local cluster launch is told that workgroup 0 sits on another XCD
+    m->cl_far_next = 1;
+    return IKF_OK;
+  }
+  if (variant == 189 || variant == 190) {  // cluster form, G = 8 / 16: a row tile's members spread over the XCDs / on one XCD (default)
+    m->cl_local = variant - 189;
+    return IKF_OK;
+  }
   if (variant == 188) {  // tests of the repair path: the next cluster launch is one workgroup short
     m->cl_drop_next = 1;
     return IKF_OK;
@@ -1102,7 +1113,7 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
 // whatever part of it is used) and the cluster form (G = 8 / 4 / 2: <= 512 / 1024 / 2048 rows at a fixed cost each).  A batch is cut into
 // consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
 // tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
-//   row-owner round 2.82;  cluster 0.285 / 0.38 / 0.53 / 0.86 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
+//   row-owner round 2.82;  cluster 0.285 / 0.36 / 0.51 / 0.86 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
 //   per-layer 0.272 / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
 //   2048 / 2560 / 3072 / 4096 rows (+ 0.10 beside the resident-row forms: another weight image, see plan_tail);  + 0.01 per extra chunk.
 // e.g. 1 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
@@ -1117,11 +1128,15 @@ static bool rowowner_allowed(const ikf_model* m) {
 }
 static bool cluster_allowed(ikf_model* m) {
   if (m->ro_stream == nullptr || m->cl_mode == 0 || m->precision != 0 || !m->loaded) return false;
-  if (m->h_cl_give_up && *m->h_cl_give_up != 0) {  // a wait of an earlier call ran out (its rows were recomputed by the repair launch):
-    m->cl_mode = 0;                                // the device is shared or partitioned - no more in-launch hand-overs on this handle
+  if (m->h_cl_give_up && *m->h_cl_give_up != 0) {  // an earlier call's cluster launch gave up (its rows were recomputed by the repair launch):
+    const int why = *m->h_cl_give_up;
     *m->h_cl_give_up = 0;
     ++m->cl_repairs;
-    return false;
+    if (why == 2) m->cl_local = 0;                 // a member of the XCD-local form met a peer on another XCD: back to the spread form
+    else {
+      m->cl_mode = 0;                              // a wait ran out: the device is shared or partitioned - no more in-launch hand-overs here
+      return false;
+    }
   }
   return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
 }
@@ -1153,7 +1168,7 @@ static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool 
     best = TailPlan{per_layer_cost(on256) + ((mixed || cl) ? 0.10 : 0.0), {{0, rows}}};
     if (ro && 2.82 < best.cost) best = TailPlan{2.82, {{1, rows}}};
     if (cl) {
-      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.38}, {8, 0.53}, {4, 0.86}, {2, 1.55}};
+      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.36}, {8, 0.51}, {4, 0.86}, {2, 1.55}};
       for (const auto& f : forms) {
         const long long cap = (round / IKF_RO_ROWS) / f.G * IKF_RO_ROWS;   // rows of a full grid of this form: whole tiles, at most one workgroup per CU
         if (cap <= 0) continue;
@@ -1265,7 +1280,10 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
   c.abort_word = c.flags + (size_t)c.n_rt * G * 32;
   c.give_up = m->h_cl_give_up;
   IKF_HIP(prof_mark(m, s));
-  IKF_HIP(launch_flow_cluster(c, G, s, m->cl_drop_next));
+  const bool local = m->cl_local != 0 && cluster_local_form(G) && cluster_grid(c.n_rt, G, true) <= (unsigned)m->n_cu;
+  c.test_far = local ? m->cl_far_next : 0;
+  if (local) m->cl_far_next = 0;
+  IKF_HIP(launch_flow_cluster(c, G, s, m->cl_drop_next, local));
   m->cl_drop_next = 0;
   IKF_HIP(prof_mark(m, s));
   // the repair launch: the same rows through the row-owner kernel, which returns at once unless a wait of the cluster launch ran out
@@ -1314,7 +1332,7 @@ static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, l
   for (const FlowChunk& c : plan) {
     ikf_status st = IKF_OK;
     if (c.form == 1) st = run_flow_rowowner(m, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
-    else if (c.form >= 2 && ((c.rows + IKF_RO_ROWS - 1) / IKF_RO_ROWS) * c.form <= m->n_cu)   // (every workgroup of a cluster launch must be resident)
+    else if (c.form >= 2 && cluster_grid((int)((c.rows + IKF_RO_ROWS - 1) / IKF_RO_ROWS), c.form, false) <= (unsigned)m->n_cu)   // (every workgroup of a cluster launch must be resident)
       st = run_flow_cluster(m, c.form, ps, d_latent, r_base, c.rows, clamp_limits, d_q_out, s);
     else {
       st = ensure_scratch(m, c.rows);

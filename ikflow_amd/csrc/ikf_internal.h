@@ -238,11 +238,15 @@ struct RcArgs {            // cluster form (k_flow_cluster<G>): G workgroups per
   unsigned* flags;         // [n_rt][G][32] epoch published by each member (one 128-byte line each) = pbuf + n_rt * G * 256 (one memset)
   unsigned* abort_word;    // device word behind the flags (same memset): set when a wait ran out - every other wait ends, and the
                            // row-owner launch queued behind this one (run_if = abort_word) recomputes the chunk
-  int* give_up;            // host-visible twin: the engine stops using the cluster form on this handle
+  int test_far;            // tests: workgroup 0 of the XCD-local form publishes a wrong XCC_ID (its peers must give up with code 2)
+  int* give_up;            // host-visible twin: 1 = a wait ran out (the engine stops using the cluster form on this handle), 2 = a member
+                           // of the XCD-local form met a peer on another XCD (the engine goes back to the spread form)
 };
 size_t cluster_xbuf_floats(int n_rt);
 size_t cluster_sync_bytes(int n_rt, int G);   // pbuf + flags + the abort word
-hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups = 0);
+hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups = 0, bool local = false);
+bool cluster_local_form(int G);                          // G = 8 / 16: a form with every member of a row tile on one XCD exists
+unsigned cluster_grid(int n_rt, int G, bool local);      // workgroups of a launch (the local form pads to whole groups of 8 row tiles)
 constexpr int IKF_RO_ROWS = 16;                       // rows per workgroup
 size_t rowowner_subnet_floats();                        // floats of one subnet's stream image
 size_t rowowner_stream_floats(int n_sub);               // whole image incl. the ring's lead padding

@@ -51,9 +51,12 @@ ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, i
  *   158 / 159        batches of <= 64 rows on 16 x 16 tiles: off / on (default); 161 forced
  *   162 / 163        129 .. 256 rows on 32 x 32 tiles built from 16x16x4 MFMAs: off (default) / on; 164 forced
  *   170 / 171        <= 128 rows: the whole subnet chain in one launch, hand-over between layers inside each XCD: off (default) / on
- *   185 / 186 / 187  cluster form for 257 .. 3327 rows (G = 8 / 4 / 2 workgroups per 16-row tile split the hidden columns and exchange
- *                    activations inside the launch): never / by the cost model (default) / whenever its grid fits; 188: tests - the next
- *                    cluster launch runs one workgroup short (exercises the repair launch)
+ *   185 / 186 / 187  cluster form for 1 .. 3327 rows (G = 32 / 16 / 8 / 4 / 2 workgroups per 16-row tile split the hidden columns and
+ *                    exchange activations inside the launch): never / by the cost model (default) / whenever its grid fits; 188: tests -
+ *                    the next cluster launch runs one workgroup short (exercises the repair launch)
+ *   189 / 190        cluster form with 8 / 16 members: a row tile's members spread over the XCDs / all on one XCD, hand-over through that
+ *                    XCD's L2 (default; the placement is verified inside the launch and the handle falls back to 189 by itself);
+ *                    191: tests - the next such launch's workgroup 0 publishes a wrong XCC_ID (exercises that fall-back)
  *   180 / 181 / 182  row-owner form (ONE launch per call; a workgroup keeps 16 rows on chip through every subnet, weights streamed
  *                    past them; width 1024, coeff_fn_config 3): never / by batch size (default: full rounds of CUs x 16 rows and a
  *                    last partial round of >= 13/16 of one) / always

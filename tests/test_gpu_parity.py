@@ -1588,6 +1588,61 @@ def test_cluster_form_repair_launch_when_a_peer_never_arrives():
     assert (again - good).abs().max().item() <= FLOW_TOL and eng.cluster_repairs == 1
 
 
+@pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 500, 512])
+def test_cluster_form_xcd_local_hand_over_equals_the_spread_form(n):
+    """G = 8 / 16: the default form keeps a row tile's members on ONE XCD and hands activations over through that XCD's L2 (plain stores);
+    ikf_set_gemm_variant 189 spreads the members over the XCDs (write-through stores, the form of the other member counts).  Same
+    arithmetic, another memory path: bit-for-bit the same results, ragged last tiles and grids padded to groups of 8 row tiles included,
+    and no repair - the placement check inside the launch found every member where the grid mapping expects it."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    _, poses = reachable_poses(robot, n, 61)
+    lat = latents(n, lay.dim, 62)
+    P, L = poses.to(DEV), lat.to(DEV)
+    assert eng.plan(n) == f"cluster{16 if n <= 256 else 8}:{n}"
+    local = [s.generate_ik_solutions(P, latent=L).clone() for _ in range(3)]
+    eng.set_gemm_variant(189)
+    spread = s.generate_ik_solutions(P, latent=L).clone()
+    eng.set_gemm_variant(190)
+    local.append(s.generate_ik_solutions(P, latent=L).clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, spread) for o in local) and eng.cluster_repairs == 0
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
+    assert (spread.cpu() - ref).abs().max().item() <= FLOW_TOL
+
+
+def test_cluster_form_xcd_local_placement_check_falls_back_to_the_spread_form():
+    """Nothing about placement is assumed: every member publishes its XCC_ID in the top byte of its epoch words, and a consumer that meets
+    another XCD's id gives up BEFORE it reads that peer's payload (which would sit in an L2 it cannot see).  ikf_set_gemm_variant 191 makes
+    workgroup 0 of the next XCD-local launch publish a wrong id: its peers give up (host word 2), the repair launch recomputes the rows - the
+    caller gets the row-owner form's results bit for bit -, the handle counts it and goes on with the SPREAD cluster form, not without the
+    cluster form."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 512
+    _, poses = reachable_poses(robot, n, 63)
+    lat = latents(n, lay.dim, 64)
+    P, L = poses.to(DEV), lat.to(DEV)
+    eng.set_gemm_variant(182)
+    ro = s.generate_ik_solutions(P, latent=L).clone()
+    eng.set_gemm_variant(181)
+    good = s.generate_ik_solutions(P, latent=L).clone()
+    assert eng.cluster_repairs == 0
+    eng.set_gemm_variant(191)
+    out = torch.full_like(good, float("nan"))
+    out.copy_(s.generate_ik_solutions(P, latent=L))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ro), "the repair launch's rows"
+    assert eng.cluster_repairs == 1 and "cluster" in eng.dominant_kernel_name(n) and eng.plan(n) == "cluster8:512"
+    again = s.generate_ik_solutions(P, latent=L)   # the spread form from now on: same bits as the local form gave
+    torch.cuda.synchronize()
+    assert torch.equal(again, good) and eng.cluster_repairs == 1
+    eng.set_gemm_variant(191)                       # (no XCD-local launch any more: the hook stays unused, nothing gives up)
+    assert torch.equal(s.generate_ik_solutions(P, latent=L), good) and eng.cluster_repairs == 1
+
+
 def test_plan_of_a_call_by_batch_size():
     """plan_flow's decisions at representative sizes (released Panda shape, 256 CUs): what DESIGN.md section 4.0 tabulates.  Other shapes
     (TINY: width 256) and the f16x3 mode stay on the per-layer kernels whatever the size."""

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   const int NB = argc > 4 ? atoi(argv[4]) : 12;
   const int D = argc > 5 ? atoi(argv[5]) : 7;
   const int G = argc > 6 ? atoi(argv[6]) : 1;
-  const int duo = argc > 7 ? atoi(argv[7]) : 0;   // 1: the half-CU form (k_flow_duo<G>, two workgroups per CU)
+  const int duo = argc > 7 ? atoi(argv[7]) : 0;   // 1: the half-CU form (k_flow_duo<G>, two workgroups per CU); 2: the XCD-local cluster form (G = 8 / 16)
   const int L1 = D / 2, L2 = D - L1, W = RO_W, ndof = 7;
   const int n_sub = 2 * NB;
   std::mt19937 rng(7);
@@ -99,7 +99,8 @@ int main(int argc, char** argv) {
   for (int k = 0; k < D; ++k) Minv[(size_t)k * D + k] = k < ndof ? 2.9f : 1.f;
   float *d_x = up(hx), *d_p = up(hp), *d_Minv = up(Minv), *d_blin = up(blin), *d_lo = up(lo), *d_hi = up(hi), *d_q;
   CK(hipMalloc(&d_q, (size_t)M * ndof * 4));
-  const unsigned grid = (M + RO_ROWS - 1) / RO_ROWS * (argc > 6 ? atoi(argv[6]) : 1);
+  const unsigned n_tiles = (M + RO_ROWS - 1) / RO_ROWS;
+  const unsigned grid = (duo == 2 ? (n_tiles + 7) / 8 * 8 : n_tiles) * (unsigned)G;   // (the XCD-local form pads to whole groups of 8 row tiles)
   unsigned long long* d_trace; CK(hipMalloc(&d_trace, (size_t)grid * 64 * 8)); CK(hipMemset(d_trace, 0, (size_t)grid * 64 * 8));
   RoArgs a{};
   a.stream = d_stream; a.stream_bytes = (unsigned)(stream_floats * 4); a.sub = d_sub; a.n_sub = n_sub; a.x0 = d_x;
@@ -117,7 +118,7 @@ int main(int argc, char** argv) {
     rc.give_up = h_give_up;
   }
   auto launch = [&]() -> hipError_t {
-    if (G > 1) { rc.ro = a; return duo ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr); }
+    if (G > 1) { rc.ro = a; return duo == 1 ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr, 0, /*local=*/duo == 2); }
     return launch_flow_rowowner(a, nbuf, nullptr);
   };
 #define launch_flow_rowowner(a_, n_, s_) launch()
