@@ -34,7 +34,8 @@ for V in "default::k_flow_rowowner" "per_layer:--gemm-variant 180:k_flow_gemm" "
   python "$REPO/tools/pmc_summarize.py" "$OUT/$NAME" $KERN $FILES
 done
 cd "$REPO"
-mkdir -p profiles && cp "$OUT/pmc_summary.json" "profiles/${R}_pmc_summary.json"   # so the bench below reports this traffic
+mkdir -p profiles
+for F in "$OUT"/pmc_summary*.json; do cp "$F" "profiles/${R}_$(basename "$F")"; done   # so the bench below reports THIS run's counters in its cells
 python bench.py > "$OUT/bench_default.log" 2>&1; tail -1 "$OUT/bench_default.log" > "$OUT/bench_default.json"
 python bench.py --precision f16x3 $COMMON 2>&1 | tail -1 > "$OUT/bench_f16x3.json"
 echo "profile_round: done -> $OUT"; ls -la "$OUT"
