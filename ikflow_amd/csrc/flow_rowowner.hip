@@ -320,10 +320,6 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr unsigned kClusterSpinLimit = 1u << 18;   // polls of (s_sleep 1 + one L2-missing load): some 0.1 s - a peer that is not resident
 
-__device__ __forceinline__ void ro_give_up_once(int* give_up) {   // 0 -> 1; a 2 (placement) already there stays
-  int expected = 0;
-  (void)__hip_atomic_compare_exchange_strong(give_up, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID
 
 // LOCAL (G = 8 / 16): every member of a row tile on ONE XCD - workgroup b is member (b / 8) % G of tile b % 8 + 8 ((b / 8) / G); with the
@@ -492,25 +488,31 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   // peer sits on another XCD - found before any of its payload is read
   auto wait_peers = [&](unsigned e) -> bool {
     if (wave == 0) {
-      unsigned ok = 1, far = 0;
+      unsigned ok = 1, far = 0, late = 0;
       if (lane < G && lane != j) {
         unsigned n = 0, w;
         while (((w = __hip_atomic_load(flags + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < e) {
           __builtin_amdgcn_s_sleep(1);
-          if ((++n & 63u) == 0 && (n > kClusterSpinLimit || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-            ok = 0;
-            break;
+          if ((++n & 63u) == 0) {
+            if (n > kClusterSpinLimit) late = 1;
+            if (late || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              ok = 0;
+              break;
+            }
           }
         }
         if (LOCAL && ok && (w >> 24) != my_xcc) far = 1;
       }
       far = __any(far != 0) ? 1u : 0u;
+      late = __any(late != 0) ? 1u : 0u;
       ok = (__all(ok != 0) && !far) ? 1u : 0u;
       if (lane == 0) {
         if (!ok) {
           __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (far) __hip_atomic_store(c.give_up, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: placement, not a lost peer)
-          else ro_give_up_once(c.give_up);
+          // the host word is written by whoever FOUND the reason (plain stores to host memory: no PCIe atomics needed); a workgroup that
+          // merely saw the abort word leaves it alone.  2: placement (the XCD-local form), 1: a peer never arrived
+          if (far) __hip_atomic_store(c.give_up, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          else if (late) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         s_ok = ok;
       }
