@@ -123,6 +123,7 @@ SIGNATURES = {
     "ikf_cluster_repairs": (C.c_int64, [C.c_void_p]),
     "ikf_probes_build": (C.c_int, []),
     "ikf_plan_describe": (C.c_int, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int]),
+    "ikf_cluster_local": (C.c_int, [C.c_void_p]),
     "ikf_plan_describe_for": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.c_int, C.c_char_p, C.c_int]),
     "ikf_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
 }

@@ -22,6 +22,8 @@
 // against the oracle.
 #include "ikf_internal.h"
 
+#include <vector>
+
 namespace ikf {
 
 typedef float ro_f4 __attribute__((ext_vector_type(4)));
@@ -806,6 +808,29 @@ static hipError_t launch_cluster_g(const RcArgs& c, unsigned grid, hipStream_t s
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_flow_cluster<G, LOCAL>), dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
   return hipGetLastError();
+}
+// Where the dispatcher puts workgroup b of a grid: the XCD-local form needs workgroups b and b + 8 k on the same XCD.  One launch of
+// n_cu single-wave workgroups, each reporting its XCC_ID; true when id(b) == id(b mod 8) for every b (8 XCDs round-robin, or any number
+// of XCDs that divides 8, or one).  Asked once per handle at load; every launch of the form still checks its own members.
+__global__ void k_xcc_census(unsigned* out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = ro_xcc_id();
+}
+hipError_t cluster_placement_census(int n_cu, bool* groups_of_8_share_an_xcd) {
+  *groups_of_8_share_an_xcd = false;
+  if (n_cu <= 0) return hipSuccess;
+  unsigned* d = nullptr;
+  hipError_t e = hipMalloc(&d, sizeof(unsigned) * n_cu);
+  if (e != hipSuccess) return e;
+  std::vector<unsigned> h(n_cu, 0xffffffffu);
+  hipLaunchKernelGGL(k_xcc_census, dim3(n_cu), dim3(64), 0, nullptr, d);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpy(h.data(), d, sizeof(unsigned) * n_cu, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return e;
+  bool ok = true;
+  for (int b = 0; b < n_cu; ++b) ok = ok && h[b] <= 0xfu && h[b] == h[b % 8];
+  *groups_of_8_share_an_xcd = ok;
+  return hipSuccess;
 }
 bool cluster_local_form(int G) { return G == 8 || G == 16; }
 unsigned cluster_grid(int n_rt, int G, bool local) { return local ? (unsigned)((n_rt + 7) / 8 * 8 * G) : (unsigned)n_rt * (unsigned)G; }

@@ -110,6 +110,7 @@ struct ikf_model {
   int* h_cl_give_up = nullptr;    // pinned, device-visible
   int cl_drop_next = 0;           // tests: the next cluster launch runs one workgroup short (ikf_set_gemm_variant 188): its tile's waits run out
   long long cl_repairs = 0;       // give-ups seen so far (ikf_cluster_repairs)
+  int cl_census_ok = -1;          // the placement census at load: workgroups b and b + 8 k share an XCD (1) or not (0); -1 not asked
   int cl_far_next = 0;            // tests (ikf_set_gemm_variant 191): the next XCD-local launch's workgroup 0 publishes a wrong XCC_ID
   int cl_local = 1;               // G = 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
                                   // peer on another XCD (placement is verified in the launch, never assumed) or by ikf_set_gemm_variant 189
@@ -486,6 +487,12 @@ static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& pe
   }
   IKF_HIP(hipMemcpy(m->d_ro_sub, tab.data(), sizeof(RoSubnet) * n_sub, hipMemcpyHostToDevice));
   IKF_HIP(hipDeviceSynchronize());
+  // the XCD-local hand-over of the cluster form (G = 8 / 16) needs workgroups b and b + 8 k of a grid on one XCD: asked of the device once
+  // (and checked again by every such launch among its own members)
+  bool grouped = false;
+  IKF_HIP(cluster_placement_census(m->n_cu, &grouped));
+  m->cl_census_ok = grouped ? 1 : 0;
+  if (!grouped) m->cl_local = 0;
   // the cluster form's exchange buffers have one size (8 MB + 1.2 MB): reserved here, so that no call ever allocates for them
   return ensure_cluster_scratch(m, 1);
 }
@@ -747,6 +754,8 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     return IKF_OK;
   }
   if (variant == 189 || variant == 190) {  // cluster form, G = 8 / 16: a row tile's members spread over the XCDs / on one XCD (default)
+    if (variant == 190 && m->cl_census_ok == 0)
+      return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_gemm_variant(190): on this device workgroups b and b + 8 k of a grid do not share an XCD");
     m->cl_local = variant - 189;
     return IKF_OK;
   }
@@ -1309,6 +1318,13 @@ extern "C" ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner
   if ((int)out.size() + 1 > buf_len) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_plan_describe_for: buffer too small");
   memcpy(buf, out.c_str(), out.size() + 1);
   return IKF_OK;
+}
+// 1: cluster launches with 8 / 16 members hand over through one XCD's L2 (the load-time placement census agreed and no launch has met a
+// member elsewhere since); 0: through memory
+extern "C" int ikf_cluster_local(ikf_model* m) {
+  if (!m) return 0;
+  (void)cluster_allowed(m);  // (folds a pending give-up word in)
+  return (m->cl_local != 0 && m->cl_mode != 0 && m->ro_stream != nullptr) ? 1 : 0;
 }
 extern "C" int64_t ikf_cluster_repairs(ikf_model* m) {
   if (!m) return 0;

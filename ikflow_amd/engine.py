@@ -414,6 +414,11 @@ class Engine:
         return buf.value.decode()
 
     @property
+    def cluster_local(self) -> bool:
+        """Cluster launches with 8 / 16 members hand over through one XCD's L2 (placement census at load + a check in every launch)."""
+        return bool(self.lib.ikf_cluster_local(self._h))
+
+    @property
     def cluster_repairs(self) -> int:
         """Calls whose cluster-form launch gave up waiting for a peer workgroup (recomputed by the repair launch; form then disabled)."""
         return int(self.lib.ikf_cluster_repairs(self._h))

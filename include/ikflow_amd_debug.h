@@ -37,6 +37,9 @@ const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
 /* The chunks a call of `rows` rows is cut into on this handle with its current settings, e.g. "rowowner:4096 cluster16:200"
  * (forms: perlayer, rowowner, cluster<G>). */
 ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len);
+/* 1 while cluster launches with 8 / 16 members keep a row tile's members on one XCD and hand over through its L2 (a placement census at
+ * load agreed, and no launch has met a member elsewhere since); 0: hand-over through memory. */
+int ikf_cluster_local(ikf_model* m);
 /* The same decision as pure host logic - no handle, no device: a chip of n_cu CUs, the released shape in f32, the row-owner launch and
  * the cluster form allowed (1) or not (0).  (CPU tests of the planner.) */
 ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, int cluster_allowed, char* buf, int buf_len);

@@ -1601,13 +1601,14 @@ def test_cluster_form_xcd_local_hand_over_equals_the_spread_form(n):
     lat = latents(n, lay.dim, 62)
     P, L = poses.to(DEV), lat.to(DEV)
     assert eng.plan(n) == f"cluster{16 if n <= 256 else 8}:{n}"
+    assert eng.cluster_local, "the placement census at load: workgroups b and b + 8 k of a grid share an XCD on an MI355X"
     local = [s.generate_ik_solutions(P, latent=L).clone() for _ in range(3)]
     eng.set_gemm_variant(189)
     spread = s.generate_ik_solutions(P, latent=L).clone()
     eng.set_gemm_variant(190)
     local.append(s.generate_ik_solutions(P, latent=L).clone())
     torch.cuda.synchronize()
-    assert all(torch.equal(o, spread) for o in local) and eng.cluster_repairs == 0
+    assert all(torch.equal(o, spread) for o in local) and eng.cluster_repairs == 0 and eng.cluster_local
     ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
     assert (spread.cpu() - ref).abs().max().item() <= FLOW_TOL
 
@@ -1629,13 +1630,13 @@ def test_cluster_form_xcd_local_placement_check_falls_back_to_the_spread_form():
     ro = s.generate_ik_solutions(P, latent=L).clone()
     eng.set_gemm_variant(181)
     good = s.generate_ik_solutions(P, latent=L).clone()
-    assert eng.cluster_repairs == 0
+    assert eng.cluster_repairs == 0 and eng.cluster_local
     eng.set_gemm_variant(191)
     out = torch.full_like(good, float("nan"))
     out.copy_(s.generate_ik_solutions(P, latent=L))
     torch.cuda.synchronize()
     assert torch.equal(out, ro), "the repair launch's rows"
-    assert eng.cluster_repairs == 1 and "cluster" in eng.dominant_kernel_name(n) and eng.plan(n) == "cluster8:512"
+    assert eng.cluster_repairs == 1 and "cluster" in eng.dominant_kernel_name(n) and eng.plan(n) == "cluster8:512" and not eng.cluster_local
     again = s.generate_ik_solutions(P, latent=L)   # the spread form from now on: same bits as the local form gave
     torch.cuda.synchronize()
     assert torch.equal(again, good) and eng.cluster_repairs == 1
