@@ -324,13 +324,13 @@ constexpr unsigned kClusterSpinLimit = 1u << 18;   // polls of (s_sleep 1 + one 
 
 __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID
 
-// LOCAL (G = 8 / 16): every member of a row tile on ONE XCD - workgroup b is member (b / 8) % G of tile b % 8 + 8 ((b / 8) / G); with the
-// observed placement b -> XCD b % 8 the tile lives on XCD b % 8 - and the hand-over goes through that XCD's L2: plain stores (they stay in
-// the L2 every member shares; the drain waits for the L2, not for memory), same epoch words, same sc1 loads (L1-bypassing).  3.4 % / 4.5 %
-// off a 512- / 256-row call; every L2 then pulls every member's weight slice (8 x the fabric traffic) - which is why G = 32 stays spread
-// (0.34 against 0.28 ms at 128 rows) and G = 4 / 2 gain nothing (1.5 % / 0).  NOTHING is assumed: a member publishes its XCC_ID in the top
-// byte of every epoch word, a consumer that meets another XCD's id gives up (abort word, host word = 2) BEFORE it reads a payload, the
-// repair launch recomputes the rows, and the handle goes back to the spread form.
+// LOCAL (G = 4 / 8 / 16): every member of a row tile on ONE XCD - workgroup b is member (b / 8) % G of tile b % 8 + 8 ((b / 8) / G); with
+// the observed placement b -> XCD b % 8 the tile lives on XCD b % 8 - and the hand-over goes through that XCD's L2: plain stores (they stay
+// in the L2 every member shares; the drain waits for the L2, not for memory), same epoch words, same sc1 loads (L1-bypassing).  2.5 % / 4 % /
+// 4.5 % off a 1024- / 512- / 256-row call; every L2 then pulls every member's weight slice (8 x the fabric traffic) - which is why G = 32
+// stays spread (0.34 against 0.28 ms at 128 rows) and G = 2 gains nothing.  NOTHING is assumed: a census at load (cluster_placement_census),
+// and in every launch a member publishes its XCC_ID in the top byte of every epoch word; a consumer that meets another XCD's id gives up
+// (abort word, host word = 2) BEFORE it reads a payload, the repair launch recomputes the rows, and the handle goes back to the spread form.
 template <int G, bool LOCAL>
 __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   constexpr int NBM = RO_KG / G;                     // 16-column blocks of one member's slice (= 16-k groups of its k range)
@@ -832,7 +832,7 @@ hipError_t cluster_placement_census(int n_cu, bool* groups_of_8_share_an_xcd) {
   *groups_of_8_share_an_xcd = ok;
   return hipSuccess;
 }
-bool cluster_local_form(int G) { return G == 8 || G == 16; }
+bool cluster_local_form(int G) { return G == 4 || G == 8 || G == 16; }
 unsigned cluster_grid(int n_rt, int G, bool local) { return local ? (unsigned)((n_rt + 7) / 8 * 8 * G) : (unsigned)n_rt * (unsigned)G; }
 hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups, bool local) {
   // (drop_workgroups > 0: tests of the repair path - the last workgroup of the spread form is not launched, its row tile's members wait in vain)
@@ -842,7 +842,7 @@ hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_w
   hipError_t e = hipMemsetAsync(c.pbuf, 0, cluster_sync_bytes(c.n_rt, G), s);
   if (e != hipSuccess) return e;
   if (G == 2) return launch_cluster_g<2, false>(c, grid, s);
-  if (G == 4) return launch_cluster_g<4, false>(c, grid, s);
+  if (G == 4) return local ? launch_cluster_g<4, true>(c, grid, s) : launch_cluster_g<4, false>(c, grid, s);
   if (G == 8) return local ? launch_cluster_g<8, true>(c, grid, s) : launch_cluster_g<8, false>(c, grid, s);
   if (G == 16) return local ? launch_cluster_g<16, true>(c, grid, s) : launch_cluster_g<16, false>(c, grid, s);
   if (G == 32) return launch_cluster_g<32, false>(c, grid, s);

@@ -112,7 +112,7 @@ struct ikf_model {
   long long cl_repairs = 0;       // give-ups seen so far (ikf_cluster_repairs)
   int cl_census_ok = -1;          // the placement census at load: workgroups b and b + 8 k share an XCD (1) or not (0); -1 not asked
   int cl_far_next = 0;            // tests (ikf_set_gemm_variant 191): the next XCD-local launch's workgroup 0 publishes a wrong XCC_ID
-  int cl_local = 1;               // G = 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
+  int cl_local = 1;               // G = 4 / 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
                                   // peer on another XCD (placement is verified in the launch, never assumed) or by ikf_set_gemm_variant 189
 
   // packed weights (one arena)
@@ -487,7 +487,7 @@ static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& pe
   }
   IKF_HIP(hipMemcpy(m->d_ro_sub, tab.data(), sizeof(RoSubnet) * n_sub, hipMemcpyHostToDevice));
   IKF_HIP(hipDeviceSynchronize());
-  // the XCD-local hand-over of the cluster form (G = 8 / 16) needs workgroups b and b + 8 k of a grid on one XCD: asked of the device once
+  // the XCD-local hand-over of the cluster form (G = 4 / 8 / 16) needs workgroups b and b + 8 k of a grid on one XCD: asked of the device once
   // (and checked again by every such launch among its own members)
   bool grouped = false;
   IKF_HIP(cluster_placement_census(m->n_cu, &grouped));
@@ -753,7 +753,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->cl_far_next = 1;
     return IKF_OK;
   }
-  if (variant == 189 || variant == 190) {  // cluster form, G = 8 / 16: a row tile's members spread over the XCDs / on one XCD (default)
+  if (variant == 189 || variant == 190) {  // cluster form, G = 4 / 8 / 16: a row tile's members spread over the XCDs / on one XCD (default)
     if (variant == 190 && m->cl_census_ok == 0)
       return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_gemm_variant(190): on this device workgroups b and b + 8 k of a grid do not share an XCD");
     m->cl_local = variant - 189;
@@ -1122,7 +1122,7 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
 // whatever part of it is used) and the cluster form (G = 8 / 4 / 2: <= 512 / 1024 / 2048 rows at a fixed cost each).  A batch is cut into
 // consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
 // tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
-//   row-owner round 2.82;  cluster 0.285 / 0.36 / 0.51 / 0.86 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
+//   row-owner round 2.82;  cluster 0.285 / 0.36 / 0.51 / 0.84 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
 //   per-layer 0.272 / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
 //   2048 / 2560 / 3072 / 4096 rows (+ 0.10 beside the resident-row forms: another weight image, see plan_tail);  + 0.01 per extra chunk.
 // e.g. 1 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
@@ -1177,7 +1177,7 @@ static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool 
     best = TailPlan{per_layer_cost(on256) + ((mixed || cl) ? 0.10 : 0.0), {{0, rows}}};
     if (ro && 2.82 < best.cost) best = TailPlan{2.82, {{1, rows}}};
     if (cl) {
-      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.36}, {8, 0.51}, {4, 0.86}, {2, 1.55}};
+      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.36}, {8, 0.51}, {4, 0.84}, {2, 1.55}};
       for (const auto& f : forms) {
         const long long cap = (round / IKF_RO_ROWS) / f.G * IKF_RO_ROWS;   // rows of a full grid of this form: whole tiles, at most one workgroup per CU
         if (cap <= 0) continue;
@@ -1319,7 +1319,7 @@ extern "C" ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner
   memcpy(buf, out.c_str(), out.size() + 1);
   return IKF_OK;
 }
-// 1: cluster launches with 8 / 16 members hand over through one XCD's L2 (the load-time placement census agreed and no launch has met a
+// 1: cluster launches with 4 / 8 / 16 members hand over through one XCD's L2 (the load-time placement census agreed and no launch has met a
 // member elsewhere since); 0: through memory
 extern "C" int ikf_cluster_local(ikf_model* m) {
   if (!m) return 0;

@@ -415,7 +415,7 @@ class Engine:
 
     @property
     def cluster_local(self) -> bool:
-        """Cluster launches with 8 / 16 members hand over through one XCD's L2 (placement census at load + a check in every launch)."""
+        """Cluster launches with 4 / 8 / 16 members hand over through one XCD's L2 (placement census at load + a check in every launch)."""
         return bool(self.lib.ikf_cluster_local(self._h))
 
     @property

@@ -37,7 +37,7 @@ const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows);
 /* The chunks a call of `rows` rows is cut into on this handle with its current settings, e.g. "rowowner:4096 cluster16:200"
  * (forms: perlayer, rowowner, cluster<G>). */
 ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len);
-/* 1 while cluster launches with 8 / 16 members keep a row tile's members on one XCD and hand over through its L2 (a placement census at
+/* 1 while cluster launches with 4 / 8 / 16 members keep a row tile's members on one XCD and hand over through its L2 (a placement census at
  * load agreed, and no launch has met a member elsewhere since); 0: hand-over through memory. */
 int ikf_cluster_local(ikf_model* m);
 /* The same decision as pure host logic - no handle, no device: a chip of n_cu CUs, the released shape in f32, the row-owner launch and
@@ -57,7 +57,7 @@ ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, i
  *   185 / 186 / 187  cluster form for 1 .. 3327 rows (G = 32 / 16 / 8 / 4 / 2 workgroups per 16-row tile split the hidden columns and
  *                    exchange activations inside the launch): never / by the cost model (default) / whenever its grid fits; 188: tests -
  *                    the next cluster launch runs one workgroup short (exercises the repair launch)
- *   189 / 190        cluster form with 8 / 16 members: a row tile's members spread over the XCDs / all on one XCD, hand-over through that
+ *   189 / 190        cluster form with 4 / 8 / 16 members: a row tile's members spread over the XCDs / all on one XCD, hand-over through that
  *                    XCD's L2 (default; the placement is verified inside the launch and the handle falls back to 189 by itself);
  *                    191: tests - the next such launch's workgroup 0 publishes a wrong XCC_ID (exercises that fall-back)
  *   180 / 181 / 182  row-owner form (ONE launch per call; a workgroup keeps 16 rows on chip through every subnet, weights streamed

@@ -1588,9 +1588,9 @@ def test_cluster_form_repair_launch_when_a_peer_never_arrives():
     assert (again - good).abs().max().item() <= FLOW_TOL and eng.cluster_repairs == 1
 
 
-@pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 500, 512])
+@pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 500, 512, 700, 1000, 1024])
 def test_cluster_form_xcd_local_hand_over_equals_the_spread_form(n):
-    """G = 8 / 16: the default form keeps a row tile's members on ONE XCD and hands activations over through that XCD's L2 (plain stores);
+    """G = 4 / 8 / 16: the default form keeps a row tile's members on ONE XCD and hands activations over through that XCD's L2 (plain stores);
     ikf_set_gemm_variant 189 spreads the members over the XCDs (write-through stores, the form of the other member counts).  Same
     arithmetic, another memory path: bit-for-bit the same results, ragged last tiles and grids padded to groups of 8 row tiles included,
     and no repair - the placement check inside the launch found every member where the grid mapping expects it."""
@@ -1600,7 +1600,7 @@ def test_cluster_form_xcd_local_hand_over_equals_the_spread_form(n):
     _, poses = reachable_poses(robot, n, 61)
     lat = latents(n, lay.dim, 62)
     P, L = poses.to(DEV), lat.to(DEV)
-    assert eng.plan(n) == f"cluster{16 if n <= 256 else 8}:{n}"
+    assert eng.plan(n) == f"cluster{16 if n <= 256 else (8 if n <= 512 else 4)}:{n}"
     assert eng.cluster_local, "the placement census at load: workgroups b and b + 8 k of a grid share an XCD on an MI355X"
     local = [s.generate_ik_solutions(P, latent=L).clone() for _ in range(3)]
     eng.set_gemm_variant(189)

@@ -7,7 +7,7 @@ MODEL = "panda__full__lp191_5.25m"
 dev = torch.device("cuda", 0)
 robot = get_robot(MODEL_DESCRIPTIONS[MODEL]["robot_name"]); hp = hparams_for(MODEL); layout = layout_from(hp, robot)
 solver = IKFlowSolver(hp, robot); solver.load_state_dict_tensors(random_state_dict(layout, robot, seed=0)); eng = solver.engine(dev)
-for rows in (129, 200, 256, 300, 512):
+for rows in (129, 200, 256, 300, 512, 600, 768, 1024):
     q = torch.tensor(robot.sample_joint_angles(rows, 0.004, np.random.default_rng(0)), device=dev); p = robot.forward_kinematics(q)
     l = torch.randn(rows, layout.dim, generator=torch.Generator().manual_seed(1)).to(dev)
     outs = {}
