@@ -15,6 +15,7 @@
 #include <vector>
 #include "../ikflow_amd/csrc/flow_rowowner.hip"
 #include "flow_duo_probe.inc"   // the half-CU cluster form: measured and dropped, kept as a probe
+#include "flow_pair_probe.inc"  // two row tiles per workgroup in lockstep (r05): measured and dropped, kept as a probe
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 using namespace ikf;
@@ -100,7 +101,7 @@ int main(int argc, char** argv) {
   float *d_x = up(hx), *d_p = up(hp), *d_Minv = up(Minv), *d_blin = up(blin), *d_lo = up(lo), *d_hi = up(hi), *d_q;
   CK(hipMalloc(&d_q, (size_t)M * ndof * 4));
   const unsigned n_tiles = (M + RO_ROWS - 1) / RO_ROWS;
-  const unsigned grid = (duo == 2 ? (n_tiles + 7) / 8 * 8 : n_tiles) * (unsigned)G;   // (the XCD-local form pads to whole groups of 8 row tiles)
+  const unsigned grid = duo == 3 ? pair_grid((int)n_tiles, G) : (duo == 2 ? (n_tiles + 7) / 8 * 8 : n_tiles) * (unsigned)G;   // (the XCD-local form pads to whole groups of 8 row tiles)
   unsigned long long* d_trace; CK(hipMalloc(&d_trace, (size_t)grid * 64 * 8)); CK(hipMemset(d_trace, 0, (size_t)grid * 64 * 8));
   RoArgs a{};
   a.stream = d_stream; a.stream_bytes = (unsigned)(stream_floats * 4); a.sub = d_sub; a.n_sub = n_sub; a.x0 = d_x;
@@ -110,15 +111,17 @@ int main(int argc, char** argv) {
   int* h_give_up = nullptr;
   if (G > 1) {
     rc.n_rt = (M + RO_ROWS - 1) / RO_ROWS;
-    CK(hipMalloc(&rc.xbuf, cluster_xbuf_floats(rc.n_rt) * 4));
-    CK(hipMalloc(&rc.pbuf, cluster_sync_bytes(rc.n_rt, G)));
-    rc.flags = reinterpret_cast<unsigned*>(rc.pbuf + (size_t)rc.n_rt * G * 256);
-    rc.abort_word = rc.flags + (size_t)rc.n_rt * G * 32;
+    const int n_rt2 = (rc.n_rt + 1) / 2 * 2;   // (the pair form's buffers hold an even number of row tiles)
+    CK(hipMalloc(&rc.xbuf, cluster_xbuf_floats(n_rt2) * 4));
+    CK(hipMalloc(&rc.pbuf, cluster_sync_bytes(n_rt2, G)));
+    const int n_rtb = duo == 3 ? n_rt2 : rc.n_rt;
+    rc.flags = reinterpret_cast<unsigned*>(rc.pbuf + (size_t)n_rtb * G * 256);
+    rc.abort_word = rc.flags + (size_t)n_rtb * G * 32;
     CK(hipHostMalloc(&h_give_up, 4, hipHostMallocMapped)); *h_give_up = 0;
     rc.give_up = h_give_up;
   }
   auto launch = [&]() -> hipError_t {
-    if (G > 1) { rc.ro = a; return duo == 1 ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr, 0, /*local=*/duo == 2); }
+    if (G > 1) { rc.ro = a; return duo == 3 ? launch_flow_pair(rc, G, nullptr) : duo == 1 ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr, 0, /*local=*/duo == 2); }
     return launch_flow_rowowner(a, nbuf, nullptr);
   };
 #define launch_flow_rowowner(a_, n_, s_) launch()
@@ -177,7 +180,7 @@ int main(int argc, char** argv) {
       max_err = std::max(max_err, fabs(q - (double)hq[(size_t)r * ndof + j]));
     }
   }
-  printf("%sG %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", duo ? "duo " : "", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
+  printf("%sG %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", duo == 3 ? "pair " : duo ? "duo " : "", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
   // timing
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) CK(launch_flow_rowowner(a, nbuf, nullptr));
@@ -242,7 +245,38 @@ int main(int argc, char** argv) {
       printf("  XCD %d: %d workgroups, mean %.1f us, %.3f GHz, mean start +%.1f us, mean end +%.1f us\n", x, n, us / n, cyc / us * 1e-3, st / n, en / n);
     }
   }
-  if (n_sub > 2) {
+  if (n_sub > 2 && duo == 3) {   // pair form: the four slots of subnet 2 (compute wave 0) and the comm team's four jobs (comm wave 0)
+    const char* cn[4] = {"A.h2", "B.h2", "A.h3 + last", "B.h3 + last"};
+    for (int k = 0; k < 4; ++k) {
+      std::vector<double> w, b;
+      for (unsigned g = 0; g < grid; ++g) {
+        const unsigned long long* p = &tr[(size_t)g * 64];
+        w.push_back((double)(p[41 + 2 * k] - p[40 + 2 * k]));
+        if (k < 3) b.push_back((double)(p[42 + 2 * k] - p[41 + 2 * k]));
+      }
+      printf("  compute slot %-12s work median %7.0f max %7.0f   then barrier wait median %6.0f max %6.0f\n", cn[k], med(w), mx(w), med(b), mx(b));
+    }
+    const char* mn_[4] = {"A: sums, coupling, first Linear", "B: sums, coupling, first Linear", "A: h2 out / in", "B: h2 out / in"};
+    for (int k = 0; k < 4; ++k) {
+      std::vector<double> v1, v2, v3;
+      for (unsigned g = 0; g < grid; ++g) {
+        const unsigned long long* p = &tr[(size_t)g * 64 + 48 + 4 * k];
+        v1.push_back((double)(p[1] - p[0])); v2.push_back((double)(p[2] - p[1])); v3.push_back((double)(p[3] - p[2]));
+      }
+      printf("  comm job %-34s publish %6.0f (max %6.0f)  poll %6.0f (max %6.0f)  rest %6.0f (max %6.0f)\n", mn_[k], med(v1), mx(v1), med(v2), mx(v2), med(v3), mx(v3));
+    }
+#ifdef RP_FINE_STAMPS
+    {
+      std::vector<double> v1, v2, v3, v4;
+      const int b0 = 56 + 4 * (RP_FINE_STAMPS - 1);
+      for (unsigned g = 0; g < grid; ++g) {
+        const unsigned long long* p = &tr[(size_t)g * 64];
+        v1.push_back((double)(p[39] - p[b0])); v2.push_back((double)(p[37] - p[39])); v3.push_back((double)(p[38] - p[37])); v4.push_back((double)(p[b0 + 1] - p[38]));
+      }
+      printf("  X2 publisher of tile %d: vmcnt(0) at entry %6.0f (max %6.0f), LDS reads %6.0f (max %6.0f), store issue + drain %6.0f (max %6.0f), flag store + stamp %6.0f (max %6.0f)\n", RP_FINE_STAMPS - 1, med(v1), mx(v1), med(v2), mx(v2), med(v3), mx(v3), med(v4), mx(v4));
+    }
+#endif
+  } else if (n_sub > 2) {
     const char* names[5] = {"first Linear", "hidden 2", "hidden 3", "last Linear", "coupling + next input rows"};
     for (int ph = 0; ph < 5; ++ph) {
       std::vector<double> v;
