@@ -121,6 +121,9 @@ SIGNATURES = {
     "ikf_dominant_kernel_name": (C.c_char_p, []),
     "ikf_dominant_kernel_for": (C.c_char_p, [C.c_void_p, C.c_int64]),
     "ikf_cluster_repairs": (C.c_int64, [C.c_void_p]),
+    "ikf_cluster_backoff": (C.c_int64, [C.c_void_p]),
+    "ikf_load_time_ms": (C.c_double, [C.c_void_p]),
+    "ikf_frag_image_time_ms": (C.c_double, [C.c_void_p]),
     "ikf_probes_build": (C.c_int, []),
     "ikf_plan_describe": (C.c_int, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int]),
     "ikf_cluster_local": (C.c_int, [C.c_void_p]),

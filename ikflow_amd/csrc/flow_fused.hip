@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
 // The next subnet's entry phase in the tail of a contraction (TailSync: tail_next_entry) and the one-launch subnet chain for <= 128 rows
 // (k_flow_chain16) - priced and rejected in round 3 (DESIGN_LOG.md section A) - live in flow_fused_probes.inc and exist only in the probes
 // library (-DIKF_PROBES).  The FUSE template parameter of the two contraction kernels below is never instantiated true in the product.
-constexpr unsigned kTailSpinLimit = 1u << 21;  // x (s_sleep 8 + one load) ~ a second: only reached when a sibling never runs
+[[maybe_unused]] constexpr unsigned kTailSpinLimit = 1u << 21;  // x (s_sleep 8 + one load) ~ a second: only reached when a sibling never runs
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void store16_wt(const __amdgpu_buffer_rsrc_t& rs, unsigned byte_off, floatx4 v) {  // write-through
@@ -1908,18 +1908,19 @@ static hipError_t launch_fg_tail(const FusedGemmArgs& a, const FuseTail& ft, hip
 
 // The in-launch hand-over needs every workgroup of the launch resident at once (a workgroup waits for its row tile's other
 // column tiles): both kernels that carry it run one workgroup per CU (LDS), so the grid may have at most 256 tiles.
-constexpr int kResidentTiles = 256;
+[[maybe_unused]] constexpr int kResidentTiles = 256;
 int fused_tail_col_tiles(int cfg, int width) { return cfg == 0 ? width / TileCfg<0>::BN : width / KBN; }
 bool fused_tail_ok(int cfg, long long rows, int width, int D, int n_out) {
 #ifndef IKF_PROBES
-  return false;
-#endif
+  return false;   // (the in-launch entry phase exists in the probes library only)
+#else
   if (cfg != 0 && cfg != kSkinnyCfg) return false;
   const int bm = cfg == 0 ? TileCfg<0>::BM : KBM, bn = cfg == 0 ? TileCfg<0>::BN : KBN;
   if (width % bn != 0 || width / 64 > 32) return false;  // (the sc1 slot loads cover the first 32 slots)
   if (cfg == kSkinnyCfg && width % (2 * KBK) != 0) return false;
   const long long tiles = ((rows + bm - 1) / bm) * (width / bn);
   return tiles <= kResidentTiles && D <= ROWBUF && n_out <= ROWBUF;
+#endif
 }
 hipError_t launch_flow_gemm_tail(int cfg, const FusedGemmArgs& a, const EntryArgs& e, const TailSync& ts, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;

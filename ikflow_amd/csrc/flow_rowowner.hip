@@ -832,7 +832,7 @@ hipError_t cluster_placement_census(int n_cu, bool* groups_of_8_share_an_xcd) {
   *groups_of_8_share_an_xcd = ok;
   return hipSuccess;
 }
-bool cluster_local_form(int G) { return G == 4 || G == 8 || G == 16; }
+bool cluster_local_form(int G) { return G == 4 || G == 8 || G == 16; }   // (G = 2 gains nothing, G = 32 is bound by its weight stream: they stay spread)
 unsigned cluster_grid(int n_rt, int G, bool local) { return local ? (unsigned)((n_rt + 7) / 8 * 8 * G) : (unsigned)n_rt * (unsigned)G; }
 hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups, bool local) {
   // (drop_workgroups > 0: tests of the repair path - the last workgroup of the spread form is not launched, its row tile's members wait in vain)

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <unordered_map>
 #include <vector>
 
@@ -87,7 +88,11 @@ struct ikf_model {
   std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
   float* split_frag_arena = nullptr;     // fragment-major copies of the split-32 images (small-batch f16-split kernel)
   std::vector<const void*> w_mid_split_frag;
-  float* wfrag_arena = nullptr;          // fragment-major images of the hidden Linear weights (small-batch kernel)
+  // fragment-major images of the hidden Linear weights (small-batch per-layer kernels, <= 512 rows): built by the first chunk that needs
+  // them, or ahead of time by ikf_reserve - a handle whose small batches run the cluster form never pays the 201 MB / the pack launches
+  float* wfrag_arena = nullptr;
+  bool wfrag_built = false;
+  double load_ms = 0.0, frag_ms = 0.0;   // host wall time of the last ikf_load_weights (device work included) / of building these images
   std::vector<const float*> w_mid_frag;  // [subnet][layer], same flattening; null when the width does not fit
 
   // Row-owner form (flow_rowowner.hip): the whole inverse pass of a batch in ONE launch, a workgroup per 16 rows, weights streamed past
@@ -98,7 +103,7 @@ struct ikf_model {
   RoSubnet* d_ro_sub = nullptr;
   int ro_mode = -1, ro_nbuf = 4;
   int n_cu = 256;
-  long long ro_min_tail = -1;  // -1: 13/16 of a round
+  long long ro_min_tail = -1;  // -1: the last partial round goes to whatever plan_tail finds cheapest; >= 0 (probes): to the row-owner launch from that many rows on
   // Cluster form (k_flow_cluster<G>, flow_rowowner.hip) for what is left below a round: G = 8 / 4 / 2 workgroups per 16-row tile split the
   // hidden columns and exchange activations inside the launch (<= 512 / 1024 / 2048 rows).  Every cluster launch is followed by a
   // predicated row-owner launch of the same rows that runs only if a wait ran out (cl_abort set): results are valid either way, and the
@@ -110,6 +115,14 @@ struct ikf_model {
   int* h_cl_give_up = nullptr;    // pinned, device-visible
   int cl_drop_next = 0;           // tests: the next cluster launch runs one workgroup short (ikf_set_gemm_variant 188): its tile's waits run out
   long long cl_repairs = 0;       // give-ups seen so far (ikf_cluster_repairs)
+  // A wait that ran out means a peer was not resident - another process's kernel held CUs just then.  That tenant may be gone a second
+  // later, so the form is not switched off for good: it sits out cl_pause plans (ikf_generate_* calls), 16 after the first give-up and
+  // twice as many after every further one (at most 65536); kClusterCleanStreak calls of the form in a row without a give-up forget the
+  // history.  ikf_cluster_backoff reports what is left of the pause.
+  long long cl_pause = 0;         // plans the form still sits out
+  long long cl_backoff = 0;       // length of the last pause (0: no give-up on record)
+  int cl_clean = 0;               // cluster calls since the last give-up
+  bool cl_used_last = false;      // the previous plan contained a cluster launch
   int cl_census_ok = -1;          // the placement census at load: workgroups b and b + 8 k share an XCD (1) or not (0); -1 not asked
   int cl_far_next = 0;            // tests (ikf_set_gemm_variant 191): the next XCD-local launch's workgroup 0 publishes a wrong XCC_ID
   int cl_local = 1;               // G = 4 / 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
@@ -439,11 +452,18 @@ static ikf_status build_split_weights(ikf_model* m) {
 
 // fragment-major images (k_wfrag_pack) of every hidden Linear weight for k_flow_gemm_skinny (rows <= 512): the second
 // copy costs width^2 * 4 B per layer (201 MB for the Panda model) of the 288 GB
+static void drop_frag_weights(ikf_model* m) {
+  if (m->wfrag_arena) { (void)hipFree(m->wfrag_arena); m->wfrag_arena = nullptr; }
+  m->w_mid_frag.assign((size_t)2 * m->desc.nb_nodes * 3, nullptr);
+  m->wfrag_built = false;
+}
 static ikf_status build_frag_weights(ikf_model* m) {
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes, W = d.width;
-  if (m->wfrag_arena) { (void)hipFree(m->wfrag_arena); m->wfrag_arena = nullptr; }
-  m->w_mid_frag.assign((size_t)2 * NB * 3, nullptr);
+  if (m->wfrag_built) return IKF_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  drop_frag_weights(m);
+  m->wfrag_built = true;   // (also when the shape has no such image: nothing to build)
   if (d.n_hidden < 2 || fused_pick_cfg(512, W) != fused_skinny_cfg()) return IKF_OK;
   const size_t per = (size_t)W * W;
   const size_t n_layers = (size_t)2 * NB * (d.n_hidden - 1);
@@ -456,50 +476,72 @@ static ikf_status build_frag_weights(ikf_model* m) {
       m->w_mid_frag[(size_t)si * 3 + l] = dst;
     }
   IKF_HIP(hipDeviceSynchronize());
+  m->chain_tab_valid = false;  // (the chain's argument table carries these pointers)
+  m->frag_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return IKF_OK;
 }
 
 // the row-owner kernel's parameter stream: every subnet's weights in execution order (block NB-1 .. 0, s1 then s2) and, inside a subnet,
 // in the order the kernel consumes them (k_rowowner_pack), plus the small per-subnet table (last-Linear bias, perm_inv, split)
 static ikf_status ensure_cluster_scratch(ikf_model* m, long long rows);
-static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& perm_host) {
-  const FlowDims& d = m->dims;
-  const int NB = m->desc.nb_nodes, n_sub = 2 * NB;
+static void drop_rowowner_stream(ikf_model* m) {
   if (m->ro_stream) { (void)hipFree(m->ro_stream); m->ro_stream = nullptr; }
   if (m->d_ro_sub) { (void)hipFree(m->d_ro_sub); m->d_ro_sub = nullptr; }
-  if (!rowowner_shape_ok(d, n_sub) || d.slope < 0.f || d.slope > 1.f) return IKF_OK;
+}
+// Nothing here is needed by the per-layer kernels: whatever fails (the second 203 MB, the census launch, the exchange buffers) leaves the
+// handle WITHOUT the resident-row forms - rowowner_allowed / cluster_allowed test ro_stream - and ikf_load_weights still succeeds; the
+// reason is kept for ikf_last_error.
+static hipError_t build_rowowner_stream_hip(ikf_model* m, const std::vector<int>& perm_host) {
+  const FlowDims& d = m->dims;
+  const int NB = m->desc.nb_nodes, n_sub = 2 * NB;
   const size_t floats = rowowner_stream_floats(n_sub);
-  if (floats * 4 >= (size_t)1 << 32) return IKF_OK;  // (one 32-bit buffer descriptor)
-  IKF_HIP(hipMalloc(&m->ro_stream, sizeof(float) * floats));
-  IKF_HIP(hipMemset(m->ro_stream, 0, sizeof(float) * floats));
-  IKF_HIP(hipMalloc(&m->d_ro_sub, sizeof(RoSubnet) * n_sub));
+  hipError_t e = hipMalloc(&m->ro_stream, sizeof(float) * floats);
+  if (e != hipSuccess) return e;
+  if ((e = hipMemset(m->ro_stream, 0, sizeof(float) * floats)) != hipSuccess) return e;
+  if ((e = hipMalloc(&m->d_ro_sub, sizeof(RoSubnet) * n_sub)) != hipSuccess) return e;
   std::vector<RoSubnet> tab(n_sub);
-  std::vector<float> b_last(16);
   for (int sidx = 0; sidx < n_sub; ++sidx) {
     const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
     const SubnetWeights& w = m->subnets[2 * b + which - 1];
-    IKF_HIP(launch_rowowner_pack(w, m->ro_stream + (size_t)sidx * rowowner_subnet_floats(), nullptr));
+    if ((e = launch_rowowner_pack(w, m->ro_stream + (size_t)sidx * rowowner_subnet_floats(), nullptr)) != hipSuccess) return e;
     RoSubnet& r = tab[sidx];
     memset(&r, 0, sizeof(r));
-    IKF_HIP(hipMemcpy(r.b_last, w.b_last, sizeof(float) * w.n_out, hipMemcpyDeviceToHost));
+    if ((e = hipMemcpy(r.b_last, w.b_last, sizeof(float) * w.n_out, hipMemcpyDeviceToHost)) != hipSuccess) return e;
     for (int k = 0; k < 16; ++k) r.perm_inv[k] = k < d.D ? perm_host[(size_t)b * d.D + k] : k;
     r.which = which; r.n_x = w.n_x; r.x_off = which == 1 ? 0 : d.L1; r.n_half = w.n_out / 2;
   }
-  IKF_HIP(hipMemcpy(m->d_ro_sub, tab.data(), sizeof(RoSubnet) * n_sub, hipMemcpyHostToDevice));
-  IKF_HIP(hipDeviceSynchronize());
+  if ((e = hipMemcpy(m->d_ro_sub, tab.data(), sizeof(RoSubnet) * n_sub, hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
   // the XCD-local hand-over of the cluster form (G = 4 / 8 / 16) needs workgroups b and b + 8 k of a grid on one XCD: asked of the device once
   // (and checked again by every such launch among its own members)
   bool grouped = false;
-  IKF_HIP(cluster_placement_census(m->n_cu, &grouped));
+  if ((e = cluster_placement_census(m->n_cu, &grouped)) != hipSuccess) return e;
   m->cl_census_ok = grouped ? 1 : 0;
   if (!grouped) m->cl_local = 0;
+  return hipSuccess;
+}
+static ikf_status build_rowowner_stream(ikf_model* m, const std::vector<int>& perm_host) {
+  const FlowDims& d = m->dims;
+  const int n_sub = 2 * m->desc.nb_nodes;
+  drop_rowowner_stream(m);
+  if (!rowowner_shape_ok(d, n_sub) || d.slope < 0.f || d.slope > 1.f) return IKF_OK;
+  if (rowowner_stream_floats(n_sub) * 4 >= (size_t)1 << 32) return IKF_OK;  // (one 32-bit buffer descriptor)
+  hipError_t e = build_rowowner_stream_hip(m, perm_host);
   // the cluster form's exchange buffers have one size (8 MB + 1.2 MB): reserved here, so that no call ever allocates for them
-  return ensure_cluster_scratch(m, 1);
+  if (e == hipSuccess && ensure_cluster_scratch(m, 1) != IKF_OK) e = hipErrorOutOfMemory;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();   // (a refused allocation is sticky only until it is read)
+    drop_rowowner_stream(m);
+    (void)fail(IKF_ERR_HIP, std::string("ikf_load_weights: the resident-row forms are not available on this handle (") + hipGetErrorString(e) +
+                                "); every batch size runs the per-layer kernels");
+  }
+  return IKF_OK;
 }
 
 extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors) {
   if (!m || !tensors) return fail(IKF_ERR_NULL_POINTER, "ikf_load_weights: null argument");
   IKF_ON_DEVICE(m)
+  const auto t_load0 = std::chrono::steady_clock::now();
   std::unordered_map<std::string, const ikf_tensor*> idx;
   for (int i = 0; i < n_tensors; ++i)
     if (tensors[i].name) idx[tensors[i].name] = &tensors[i];
@@ -639,15 +681,18 @@ extern "C" ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, 
   // must see the NEW weights (the <= 512-row kernels read the fragment-major copy).
   m->loaded = false;
   m->chain_tab_valid = false;  // (the chain's argument table points into the weight arenas)
-  ikf_status fst = build_frag_weights(m);
-  if (fst != IKF_OK) return fst;
-  fst = build_rowowner_stream(m, perm_host);
+  drop_frag_weights(m);        // (rebuilt from the new arena by the first chunk that needs them, or by ikf_reserve)
+  ikf_status fst = build_rowowner_stream(m, perm_host);
   if (fst != IKF_OK) return fst;
   m->loaded = true;
+  m->cl_pause = m->cl_backoff = 0;
+  m->cl_clean = 0;
   if (m->precision == 1) {
     ikf_status sst = build_split_weights(m);  // refusal: precision falls back to f32, the handle stays usable
     if (sst != IKF_OK) return sst;
   }
+  IKF_HIP(hipDeviceSynchronize());
+  m->load_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load0).count();
   return IKF_OK;
 }
 
@@ -710,11 +755,16 @@ static ikf_status ensure_exact(ikf_model* m, long long poses, long long rows) {
 // small (ikf_set_exact_upfront_rows, default 32 Mi rows); beyond that a call starts with round 0's rows and grows per round from the measured survivor count, so a
 // large n with a big last-round repeat but few survivors neither allocates nor is rejected for the worst case.
 
+static bool rowowner_allowed_fwd(const ikf_model* m);
+static bool cluster_allowed_now(const ikf_model* m);
 extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_reserve: null model");
   if (max_rows < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_reserve: max_rows must be positive");
   IKF_ON_DEVICE(m)
-  return ensure_scratch(m, max_rows);
+  ikf_status st = ensure_scratch(m, max_rows);
+  // the small-batch per-layer kernels' weight image, if any call on this handle can reach them (otherwise the first such chunk builds it)
+  if (st == IKF_OK && m->loaded && !m->wfrag_built && !(rowowner_allowed_fwd(m) && cluster_allowed_now(m))) st = build_frag_weights(m);
+  return st;
 }
 
 extern "C" int ikf_probes_build(void) {
@@ -805,7 +855,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused by batch size, 101..108 fused with tile configuration 0..7, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on, 158 / 159 16 x 16 tiles for <= 64 rows off / on, 160 / 161 / 164 small-batch tile configurations 9 / 10 / 11 forced, 162 / 163 configuration 11 for 129..256 rows off / on, 170 / 171 one-launch subnet chain for <= 128 rows off / on; see include/ikflow_amd.h)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused by batch size, 101..108 fused with tile configuration 0..7, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on, 158 / 159 16 x 16 tiles for <= 64 rows off / on, 160 / 161 / 164 small-batch tile configurations 9 / 10 / 11 forced, 162 / 163 configuration 11 for 129..256 rows off / on, 170 / 171 one-launch subnet chain for <= 128 rows off / on, 180 / 181 / 182 row-owner launch never / by plan / always, 185 / 186 / 187 cluster form never / by plan / whenever the grid fits, 188 / 191 tests of its repair paths, 189 / 190 its members spread / on one XCD; see include/ikflow_amd_debug.h)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -956,6 +1006,10 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
+  if (!m->wfrag_built && (nr <= 512 || m->tile_cfg >= 0)) {   // first small chunk on this path since the weights were loaded (or ikf_reserve did it)
+    ikf_status fst = build_frag_weights(m);
+    if (fst != IKF_OK) return fst;
+  }
   if (chain_usable(m, nr)) {
     if (m->chain_census < 0) {
       ikf_status cst = chain_census(m, s);
@@ -1135,20 +1189,38 @@ static bool rowowner_allowed(const ikf_model* m) {
   return m->ro_stream != nullptr && m->ro_mode != 0 && m->precision == 0 && m->loaded &&
          (m->ro_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0));
 }
-static bool cluster_allowed(ikf_model* m) {
-  if (m->ro_stream == nullptr || m->cl_mode == 0 || m->precision != 0 || !m->loaded) return false;
-  if (m->h_cl_give_up && *m->h_cl_give_up != 0) {  // an earlier call's cluster launch gave up (its rows were recomputed by the repair launch):
-    const int why = *m->h_cl_give_up;
-    *m->h_cl_give_up = 0;
-    ++m->cl_repairs;
-    if (why == 2) m->cl_local = 0;                 // a member of the XCD-local form met a peer on another XCD: back to the spread form
-    else {
-      m->cl_mode = 0;                              // a wait ran out: the device is shared or partitioned - no more in-launch hand-overs here
-      return false;
-    }
+static const long long kClusterFirstPause = 16, kClusterMaxPause = 65536;
+static const int kClusterCleanStreak = 64;
+// folds a pending give-up word into the handle's state (no side effect otherwise)
+static void cluster_fold_give_up(ikf_model* m) {
+  if (!m->h_cl_give_up || *m->h_cl_give_up == 0) return;
+  // an earlier call's cluster launch gave up (its rows were recomputed by the repair launch)
+  const int why = *m->h_cl_give_up;
+  *m->h_cl_give_up = 0;
+  ++m->cl_repairs;
+  m->cl_clean = 0;
+  if (why == 2) m->cl_local = 0;                 // a member of the XCD-local form met a peer on another XCD: back to the spread form
+  else {                                         // a wait ran out: somebody else held CUs - sit out, twice as long as the last time
+    m->cl_backoff = m->cl_backoff == 0 ? kClusterFirstPause : (m->cl_backoff * 2 < kClusterMaxPause ? m->cl_backoff * 2 : kClusterMaxPause);
+    m->cl_pause = m->cl_backoff;
   }
+}
+static bool cluster_allowed_now(const ikf_model* m) {
+  if (m->ro_stream == nullptr || m->cl_mode == 0 || m->precision != 0 || !m->loaded || m->cl_pause > 0) return false;
   return m->cl_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0 && m->ro_mode != 0);
 }
+// the planner's question, asked once per plan: counts the pause down and the clean streak up
+static bool cluster_allowed(ikf_model* m) {
+  cluster_fold_give_up(m);
+  if (m->cl_used_last && m->cl_pause == 0 && m->cl_backoff != 0 && ++m->cl_clean >= kClusterCleanStreak) m->cl_backoff = 0;
+  m->cl_used_last = false;
+  if (m->cl_pause > 0) {
+    --m->cl_pause;
+    return false;
+  }
+  return cluster_allowed_now(m);
+}
+static bool rowowner_allowed_fwd(const ikf_model* m) { return rowowner_allowed(m); }
 static double per_layer_cost(long long rows_on_256) {
   static const struct { long long rows; double ms; } t[] = {{1, 0.272}, {16, 0.305}, {64, 0.316}, {128, 0.367}, {256, 0.52}, {512, 0.71}, {1024, 1.04},
                                                             {2048, 1.75}, {2560, 2.56}, {3072, 2.62}, {4096, 3.20}};
@@ -1207,7 +1279,17 @@ static std::vector<FlowChunk> plan_rows(long long rows, int n_cu, bool ro, bool 
     for (int g = 32; g >= 2; g /= 2)
       if (rows <= (long long)(n_cu / g) * IKF_RO_ROWS) return {{g, rows}};
   }
-  const long long full = ro ? rows / round * round : 0;
+  long long full = ro ? rows / round * round : 0;
+  if (!ro && cl && rows > round) {
+    // no row-owner launch to take the full rounds: whole 2-member cluster launches (the cheapest form per row) are peeled off here, one
+    // chunk each, and plan_tail only sees what is left below a round (its recursion is one level per full launch)
+    const long long cap2 = (round / IKF_RO_ROWS) / 2 * IKF_RO_ROWS;
+    while (cap2 > 0 && rows - full > round) {
+      plan.push_back({2, cap2});
+      full += cap2;
+    }
+  }
+  const bool peeled = !ro && full > 0;
   std::vector<FlowChunk> tail;
   if (rows - full > 0) {
     if (ro && ro_min_tail >= 0) {
@@ -1218,17 +1300,22 @@ static std::vector<FlowChunk> plan_rows(long long rows, int n_cu, bool ro, bool 
       tail = plan_tail(rows - full, round, ro, cl, full > 0, memo).chunks;
     }
   }
-  if (full > 0) plan.push_back({1, full});
+  if (full > 0 && !peeled) plan.push_back({1, full});
   for (const FlowChunk& c : tail) {
     if (!plan.empty() && plan.back().form == 1 && c.form == 1) plan.back().rows += c.rows;   // the partial round rides in the same launch
     else plan.push_back(c);
   }
   return plan;
 }
-static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows) {
+// `consume`: this plan is about to run (it counts against a pause of the cluster form); the describing entry points pass false
+static std::vector<FlowChunk> plan_flow(ikf_model* m, long long rows, bool consume = false) {
   if (rows <= 0) return {};
-  const bool ro = rowowner_allowed(m), cl = cluster_allowed(m);
-  return plan_rows(rows, m->n_cu, ro, cl, m->ro_mode, m->cl_mode, m->ro_min_tail);
+  cluster_fold_give_up(m);
+  const bool ro = rowowner_allowed(m), cl = consume ? cluster_allowed(m) : cluster_allowed_now(m);
+  std::vector<FlowChunk> plan = plan_rows(rows, m->n_cu, ro, cl, m->ro_mode, m->cl_mode, m->ro_min_tail);
+  if (consume)
+    for (const FlowChunk& c : plan) m->cl_used_last = m->cl_used_last || c.form >= 2;
+  return plan;
 }
 static std::string plan_text(const std::vector<FlowChunk>& plan) {
   std::string out;
@@ -1323,14 +1410,24 @@ extern "C" ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner
 // member elsewhere since); 0: through memory
 extern "C" int ikf_cluster_local(ikf_model* m) {
   if (!m) return 0;
-  (void)cluster_allowed(m);  // (folds a pending give-up word in)
+  cluster_fold_give_up(m);
   return (m->cl_local != 0 && m->cl_mode != 0 && m->ro_stream != nullptr) ? 1 : 0;
 }
 extern "C" int64_t ikf_cluster_repairs(ikf_model* m) {
   if (!m) return 0;
-  (void)cluster_allowed(m);  // (folds a pending give-up word in)
+  cluster_fold_give_up(m);
   return (int64_t)m->cl_repairs;
 }
+// calls the cluster form still sits out after a wait of one of its launches ran out (0: in use / never paused)
+extern "C" int64_t ikf_cluster_backoff(ikf_model* m) {
+  if (!m) return 0;
+  cluster_fold_give_up(m);
+  return (int64_t)m->cl_pause;
+}
+// host wall time of the last ikf_load_weights (pack launches and the device-side images included) and of building the small-batch
+// per-layer kernels' weight image (0 until a chunk or ikf_reserve needed it)
+extern "C" double ikf_load_time_ms(const ikf_model* m) { return m ? m->load_ms : 0.0; }
+extern "C" double ikf_frag_image_time_ms(const ikf_model* m) { return m ? m->frag_ms : 0.0; }
 extern "C" const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows) {
   if (m && rows > 0) {
     long long by_form[3] = {0, 0, 0};
@@ -1342,7 +1439,7 @@ extern "C" const char* ikf_dominant_kernel_for(const ikf_model* m, int64_t rows)
 }
 static ikf_status run_flow(ikf_model* m, PoseSource ps, const float* d_latent, long long rows, int clamp_limits,
                            float* d_q_out, hipStream_t s) {
-  const std::vector<FlowChunk> plan = plan_flow(m, rows);
+  const std::vector<FlowChunk> plan = plan_flow(m, rows, /*consume=*/true);
   const bool fused = fused_ok(m);
   long long r_base = 0;
   for (const FlowChunk& c : plan) {
@@ -1697,6 +1794,10 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
   hipStream_t s = static_cast<hipStream_t>(stream);
   st = ensure_scratch(m, rows);
   if (st != IKF_OK) return st;
+  if (rows <= 512 || m->tile_cfg >= 0) {
+    st = build_frag_weights(m);
+    if (st != IKF_OK) return st;
+  }
   if (rows > m->chunk_rows) rows = m->chunk_rows;
   const SubnetWeights& w = m->subnets[0];
   const int variant = pick_variant(m, rows);

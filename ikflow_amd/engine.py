@@ -420,8 +420,24 @@ class Engine:
 
     @property
     def cluster_repairs(self) -> int:
-        """Calls whose cluster-form launch gave up waiting for a peer workgroup (recomputed by the repair launch; form then disabled)."""
+        """Calls whose cluster-form launch gave up waiting for a peer workgroup (recomputed by the repair launch; the form then sits out
+        `cluster_backoff` calls and is tried again)."""
         return int(self.lib.ikf_cluster_repairs(self._h))
+
+    @property
+    def cluster_backoff(self) -> int:
+        """Calls the cluster form still sits out after a give-up (16 after the first, doubling up to 65536; 0: in use)."""
+        return int(self.lib.ikf_cluster_backoff(self._h))
+
+    @property
+    def load_time_ms(self) -> float:
+        """Host wall time of the last ikf_load_weights on this handle (packing, upload, device-side images of the resident-row forms)."""
+        return float(self.lib.ikf_load_time_ms(self._h))
+
+    @property
+    def frag_image_time_ms(self) -> float:
+        """... of building the small-batch per-layer kernels' weight image (0 until a <= 512-row chunk on that path or ikf_reserve needed it)."""
+        return float(self.lib.ikf_frag_image_time_ms(self._h))
 
     def dominant_kernel_name(self, rows: Optional[int] = None) -> str:
         """Name (as in a rocprofv3 kernel trace) of the kernel that carries a batch of `rows` rows; None: the per-layer contraction."""

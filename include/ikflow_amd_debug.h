@@ -40,6 +40,15 @@ ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len)
 /* 1 while cluster launches with 4 / 8 / 16 members keep a row tile's members on one XCD and hand over through its L2 (a placement census at
  * load agreed, and no launch has met a member elsewhere since); 0: hand-over through memory. */
 int ikf_cluster_local(ikf_model* m);
+/* Calls the cluster form still sits out on this handle: a wait inside one of its launches ran out (another process's kernel held CUs; the
+ * rows were recomputed by the repair launch and ikf_cluster_repairs counted it), so the form pauses for 16 calls, twice as many after every
+ * further give-up (at most 65536), and is tried again afterwards; 64 clean cluster calls in a row forget the history.  0: in use. */
+int64_t ikf_cluster_backoff(ikf_model* m);
+/* What first use costs: host wall time (ms) of the last ikf_load_weights on this handle - the packing, the upload and the device-side
+ * images of the resident-row forms included - and of building the small-batch per-layer kernels' weight image, which only the first
+ * <= 512-row chunk on that path (or ikf_reserve on a handle that can reach it) builds; 0 until then. */
+double ikf_load_time_ms(const ikf_model* m);
+double ikf_frag_image_time_ms(const ikf_model* m);
 /* The same decision as pure host logic - no handle, no device: a chip of n_cu CUs, the released shape in f32, the row-owner launch and
  * the cluster form allowed (1) or not (0).  (CPU tests of the planner.) */
 ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, int cluster_allowed, char* buf, int buf_len);
@@ -61,8 +70,8 @@ ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, i
  *                    XCD's L2 (default; the placement is verified inside the launch and the handle falls back to 189 by itself);
  *                    191: tests - the next such launch's workgroup 0 publishes a wrong XCC_ID (exercises that fall-back)
  *   180 / 181 / 182  row-owner form (ONE launch per call; a workgroup keeps 16 rows on chip through every subnet, weights streamed
- *                    past them; width 1024, coeff_fn_config 3): never / by batch size (default: full rounds of CUs x 16 rows and a
- *                    last partial round of >= 13/16 of one) / always
+ *                    past them; width 1024, coeff_fn_config 3): never / by the cost model (default: full rounds of CUs x 16 rows, and a
+ *                    last partial round when nothing cheaper covers it) / always
  * Returns IKF_ERR_BAD_ARGUMENT if unknown. */
 ikf_status ikf_set_gemm_variant(ikf_model* m, int variant);
 

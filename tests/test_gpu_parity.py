@@ -6,6 +6,8 @@ by the fp64 twin; FK 2e-6; LM step vs the fp64 twin 5e-6 (the kernel solves in f
 import os
 
 import numpy as np
+import time
+
 import pytest
 import torch
 
@@ -1584,8 +1586,89 @@ def test_cluster_form_repair_launch_when_a_peer_never_arrives():
     torch.cuda.synchronize()
     assert torch.equal(out, ro), "the repair launch's rows"
     assert eng.cluster_repairs == 1 and "cluster" not in eng.dominant_kernel_name(n)
-    again = s.generate_ik_solutions(P, latent=L)   # per-layer kernels from now on
+    again = s.generate_ik_solutions(P, latent=L)   # the form sits out the next calls
     assert (again - good).abs().max().item() <= FLOW_TOL and eng.cluster_repairs == 1
+
+
+@pytest.mark.gpu
+def test_cluster_form_is_tried_again_after_a_pause_that_doubles():
+    """A wait that ran out means another tenant held CUs at that moment - not for ever.  After a give-up the cluster form sits out 16
+    calls (ikf_cluster_backoff counts them down), then runs again at its usual speed with the cluster form's own bits; a second give-up
+    pauses 32 calls.  Results are valid throughout (repair launch / the other forms), ikf_cluster_repairs keeps counting, and reloading
+    the weights forgets the history."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 512
+    _, poses = reachable_poses(robot, n, 127)
+    lat = latents(n, lay.dim, 128)
+    P, L = poses.to(DEV), lat.to(DEV)
+    good = s.generate_ik_solutions(P, latent=L).clone()
+    assert eng.plan(n) == "cluster8:512" and eng.cluster_backoff == 0
+    for round_, pause in ((1, 16), (2, 32)):
+        eng.set_gemm_variant(188)              # the next cluster launch is one workgroup short: its tile's waits run out
+        out = s.generate_ik_solutions(P, latent=L).clone()
+        torch.cuda.synchronize()
+        assert (out - good).abs().max().item() <= FLOW_TOL
+        assert eng.cluster_repairs == round_ and eng.cluster_backoff == pause
+        assert "cluster" not in eng.plan(n), eng.plan(n)
+        for k in range(pause):
+            assert eng.cluster_backoff == pause - k
+            out = s.generate_ik_solutions(P, latent=L)
+            assert (out - good).abs().max().item() <= FLOW_TOL
+        assert eng.cluster_backoff == 0 and eng.plan(n) == "cluster8:512"
+        back = s.generate_ik_solutions(P, latent=L).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(back, good), "the cluster form again, bit for bit"
+        assert eng.cluster_repairs == round_
+    # ... and at its usual speed (0.50 ms on an idle MI355X; the per-layer kernels it replaced during the pause take 0.71)
+    for _ in range(20):
+        s.generate_ik_solutions(P, latent=L)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        s.generate_ik_solutions(P, latent=L)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    assert ms <= 0.62, f"{ms:.3f} ms per 512-row call after the pause"
+    s.load_state_dict_tensors(sd)
+    assert s.engine(DEV).cluster_backoff == 0
+
+
+@pytest.mark.gpu
+def test_small_batch_weight_image_is_built_on_first_use_only():
+    """The fragment-major image of the small-batch per-layer kernels (+ 201 MB for Panda, 48 pack launches) is no longer part of
+    ikf_load_weights: a handle whose small batches run the cluster form never builds it; the first <= 512-row chunk that does take the
+    per-layer path builds it (same results as before), and ikf_reserve does so ahead of time on a handle that can reach that path."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 200
+    _, poses = reachable_poses(robot, n, 131)
+    lat = latents(n, lay.dim, 132)
+    P, L = poses.to(DEV), lat.to(DEV)
+    assert eng.load_time_ms > 0.0 and eng.frag_image_time_ms == 0.0
+    by_plan = s.generate_ik_solutions(P, latent=L).clone()
+    assert eng.plan(n).startswith("cluster") and eng.frag_image_time_ms == 0.0
+    eng.reserve(4096)
+    assert eng.frag_image_time_ms == 0.0, "no call on this handle reaches the per-layer kernels"
+    eng.set_gemm_variant(180)
+    eng.set_gemm_variant(185)
+    assert eng.plan(n) == f"perlayer:{n}"
+    per_layer = s.generate_ik_solutions(P, latent=L).clone()
+    torch.cuda.synchronize()
+    assert eng.frag_image_time_ms > 0.0
+    assert (per_layer - by_plan).abs().max().item() <= FLOW_TOL
+    ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
+    assert (per_layer.cpu() - ref).abs().max().item() <= FLOW_TOL
+    # a handle that starts on the per-layer path: ikf_reserve builds the image before the first call
+    s2 = _solver(robot, hp, sd)
+    e2 = s2.engine(DEV)
+    e2.set_gemm_variant(180)
+    e2.set_gemm_variant(185)
+    e2.reserve(512)
+    assert e2.frag_image_time_ms > 0.0
+    assert torch.equal(s2.generate_ik_solutions(P, latent=L), per_layer)
 
 
 @pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 500, 512, 700, 1000, 1024])

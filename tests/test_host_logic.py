@@ -385,3 +385,16 @@ def test_planner_decisions_and_invariants_host_side():
             assert sum(1 for f, _ in chunks if f == "rowowner") <= 1 and (chunks[0][0] == "rowowner" or rows < round_rows), (n_cu, rows, chunks)
             checked += 1
     assert (time.perf_counter() - t0) / checked < 1e-3   # planned on the host in front of every call
+    # without the row-owner launch (a forced tile variant, ikf_set_gemm_variant 180 + 187) the cluster form takes the whole batch: full
+    # 2-member launches are peeled off iteratively - a million rows once overflowed the stack of the recursive tail planner
+    big = 16 * 1024 * 1024 * 2
+    buf = ctypes.create_string_buffer(big)
+    for n_cu in (256, 64):
+        for rows in (1_000_000, 10_000_000):
+            t0 = time.perf_counter()
+            assert lib.ikf_plan_describe_for(n_cu, rows, 0, 1, buf, big) == 0
+            dt = time.perf_counter() - t0
+            chunks = [c.split(":") for c in buf.value.decode().split()]
+            assert sum(int(r) for _, r in chunks) == rows and all(f.startswith("cluster") for f, _ in chunks)
+            assert all((int(r) + 15) // 16 * int(f[len("cluster"):]) <= n_cu for f, r in chunks)
+            assert dt < 0.5, dt
