@@ -758,6 +758,15 @@ def main():
         return p, l, ShardedStepper(lambda: solver.generate_ik_solutions(p, latent=l), world, rank, rows, layout.ndof, dev, use_dist)
 
     poses, latent, stepper = workload(B)
+    # what first use costs (outside the timed region; tools/first_use.py is the stand-alone twin): ikf_load_weights on the host clock -
+    # packing, upload, the resident-row forms' device-side image - and the handle's first call of this size, synchronised
+    torch.cuda.synchronize(dev)
+    t_first = time.perf_counter()
+    stepper.step()
+    stepper.fence()
+    first_use = {"ikf_load_weights_ms": round(eng.load_time_ms, 2), "first_call_ms": round((time.perf_counter() - t_first) * 1e3, 3),
+                 "note": "first_call_ms: one synchronised step right after the load (clocks at idle, code objects cold); the small-batch "
+                         "per-layer kernels' weight image (+ 201 MB, ~3 ms) is built only by the first <= 512-row chunk that takes that path"}
     elapsed, sol = timed_steps(stepper, args.steps, args.warmup)
     assert bool(torch.isfinite(sol).all())
     rccl = None
@@ -769,7 +778,8 @@ def main():
     #     launch = rows of the launch x SURVEY 8(d)'s 101,572,608 FLOP per solution (every Linear of every subnet);
     #   per-layer form (k_flow_gemm: one hidden Linear of all rows per launch): 2 x rows x width^2.
     dom_kernel = eng.dominant_kernel_name(B)
-    row_owner = "rowowner" in dom_kernel
+    # (the cluster form is a resident-row form like the row-owner launch: one timed launch per chunk of the plan does the whole pass)
+    row_owner = "rowowner" in dom_kernel or "cluster" in dom_kernel
     eng.profile_begin()  # (a throw-away pass first: the event pool's first allocations stay out of the measured pairs)
     stepper.step()
     eng.profile_end()
@@ -781,7 +791,7 @@ def main():
     eng.profile_begin()
     gemm_layers = 2 * layout.nb_nodes * (layout.n_hidden - 1)
     chunks = (B + 16383) // 16384  # the per-layer engine processes a call in chunks of <= 16384 rows
-    launches_per_step = 1 if row_owner else gemm_layers * chunks
+    launches_per_step = len(eng.plan(B).split()) if row_owner else gemm_layers * chunks
     prof_steps = max(1, min(10, max(2, args.steps), 8000 // launches_per_step))  # the event pool holds 8192 pairs
     sol_last = sol
     for _ in range(prof_steps):
@@ -809,7 +819,7 @@ def main():
     flow_tflops = value / world * layout.flops_per_solution() / 1e12
 
     headline_cfg = args.batch == 4096 and args.model == MODEL and args.precision == "f32"
-    ksub = "k_flow_rowowner" if row_owner else "k_flow_gemm<"
+    ksub = ("k_flow_rowowner" if "rowowner" in dom_kernel else "k_flow_cluster") if row_owner else "k_flow_gemm<"
     traffic, traffic_src = pmc_traffic_per_launch(ksub) if headline_cfg else (None, None)
     prof_us, prof_src = rocprof_kernel_avg_us(ksub) if headline_cfg else (None, None)
     live = {"traffic": None, "avg_us": None, "note": "not run", "occupancy_waves_per_simd": None, "mfma_busy_frac_of_launch": None}
@@ -819,7 +829,7 @@ def main():
     if live["avg_us"] is not None:
         prof_us, prof_src = live["avg_us"], "rocprofv3 --kernel-trace --stats in this run"
     extra = {"flow_tflops_per_gpu": round(flow_tflops, 2), "frac_of_fp32_mfma_peak_end_to_end": round(flow_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
-             "gemm_ms": round(gemm_ms, 5), "gemm_launches_per_step": launches_per_step}
+             "gemm_ms": round(gemm_ms, 5), "gemm_launches_per_step": launches_per_step, "first_use": first_use}
     if args.precision == "f32" and not args.no_split_extra:
         # the same workload with the hidden contractions on the error-compensated 3x f16 MFMA split (opt-in precision mode;
         # measured closer to the fp64 twin than the f32 MFMA path - tests/test_gpu_parity.py::test_flow_f16_split_*).
