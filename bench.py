@@ -75,53 +75,12 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------------
 # the multi-rank step: row shard -> (compute) -> one all-gather on a side stream, double buffered
 # ---------------------------------------------------------------------------------------------------------------------
-class ShardedStepper:
-    """One step = `compute()` on this rank's row shard, then the path's one collective: all_gather_into_tensor of the
-    [B x C] result.  On the GPU the gather runs on its own stream behind an event, so the gather of step i overlaps the
-    flow of step i+1; `fence()` drains both streams and barriers.  On CPU tensors (gloo dry run) the same calls run inline."""
+def ShardedStepper(compute, world, rank, rows, cols, device, use_dist, n_buf=2):
+    """The library form (ikflow_amd/dist.py::ShardedStepper): compute() on this rank's shard, the one all-gather per step on a side
+    stream, double buffered.  (tests only: gloo with device tensors drains the producer stream before its host staging.)"""
+    from ikflow_amd.dist import ShardedStepper as _Stepper
 
-    def __init__(self, compute, world, rank, rows, cols, device, use_dist, n_buf=2):
-        self.compute, self.world, self.rank, self.rows, self.device, self.use_dist = compute, world, rank, rows, device, use_dist
-        self.cuda = torch.device(device).type == "cuda"
-        self.n_buf = n_buf
-        self.i = 0
-        self.keep = [None] * n_buf
-        self.gathered = [torch.empty((world * rows, cols), dtype=torch.float32, device=device) for _ in range(n_buf)] if use_dist else None
-        self.comm_stream = torch.cuda.Stream(device) if (use_dist and self.cuda) else None
-
-    def step(self):
-        sol = self.compute()
-        if self.use_dist:
-            import torch.distributed as dist
-
-            k = self.i % self.n_buf
-            self.i += 1
-            if self.comm_stream is not None:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                self.comm_stream.wait_event(ev)
-                if TEST_BACKEND == "gloo":  # tests only: gloo's host staging does not reliably wait for the stream it is issued on (ikflow_amd/dist.py)
-                    ev.synchronize()
-                with torch.cuda.stream(self.comm_stream):
-                    dist.all_gather_into_tensor(self.gathered[k], sol)
-                sol.record_stream(self.comm_stream)
-            else:
-                dist.all_gather_into_tensor(self.gathered[k], sol)
-            self.keep[k] = sol
-        return sol
-
-    def fence(self):
-        if self.use_dist:
-            import torch.distributed as dist
-
-            if self.comm_stream is not None:
-                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
-            dist.barrier()
-        if self.cuda:
-            torch.cuda.synchronize(self.device)
-
-    def last_gathered(self):
-        return self.gathered[(self.i - 1) % self.n_buf] if self.use_dist else None
+    return _Stepper(compute, world, rank, rows, cols, device, use_dist, n_buf=n_buf, sync_before_gather=(TEST_BACKEND == "gloo"))
 
 
 def timed_steps(stepper, steps, warmup):

@@ -4,11 +4,18 @@ process group's backend is "nccl"; the same code runs on "gloo" for the CPU test
 
 The reference has no distributed code at all (no NCCL/MPI call sites); this is the MI355X-native addition the
 north star asks for ("huge pose batches shard embarrassingly across the 8 GPUs of one node with a single RCCL gather").
+
+Two families of entry points:
+  * full-tensor forms (`sharded_rows`, `sharded_generate_ik_solutions`, `sharded_generate_exact_ik_solutions`): every rank passes the SAME
+    full [n x 7] pose tensor and only touches its block - the form parity runs use (identical seeds give the single-process result);
+  * shard-in forms (`*_from_shard`, `ShardedStepper`): a rank holds ONLY its own block - poses generated or loaded in place, latents drawn
+    in place from `base_seed + rank` (SURVEY 8(e) "Determinism") - so nothing of size O(n) is replicated except the gathered result
+    itself.  `bench.py` (weak, --global-batch, --million) steps through `ShardedStepper`.
 """
 from __future__ import annotations
 
 import os
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 # RCCL exchanges peer memory handles when the group forms; this host driver supports the dmabuf form only.  Harmless when the
 # launcher already exported it; it has to be in the environment before the HIP runtime initialises.
@@ -50,6 +57,125 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
         l, h = shard_bounds(n_total, world, r)
         pieces.append(out[r * rows_max : r * rows_max + (h - l)])
     return torch.cat(pieces, dim=0)
+
+
+def gather_blocks(local: torch.Tensor, group=None, counts: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """All-gather row blocks of ANY sizes, rank order = row order, into the full tensor on every rank.  `counts` (rows of every rank's
+    block) when the caller knows them; otherwise they are exchanged first (one all-gather of `world` int64 - the only extra collective of
+    the shard-in forms).  The payload itself moves in one padded all_gather_into_tensor."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if counts is None:
+        mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        every = torch.empty(world, dtype=torch.int64, device=local.device)
+        if local.is_cuda and dist.get_backend(group) == "gloo":
+            torch.cuda.current_stream(local.device).synchronize()
+        dist.all_gather_into_tensor(every, mine, group=group)
+        counts = [int(c) for c in every.tolist()]
+    counts = [int(c) for c in counts]
+    assert len(counts) == world and counts[rank] == local.shape[0], f"rank {rank}: block of {local.shape[0]} rows, counts say {counts}"
+    rows_max = max(counts) if counts else 0
+    cols = tuple(local.shape[1:])
+    if rows_max == 0:
+        return torch.empty((0,) + cols, dtype=local.dtype, device=local.device)
+    if local.shape[0] == rows_max:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((rows_max,) + cols, dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    out = torch.empty((world * rows_max,) + cols, dtype=local.dtype, device=local.device)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream(local.device).synchronize()   # (see gather_rows)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if all(c == rows_max for c in counts):
+        return out
+    return torch.cat([out[r * rows_max : r * rows_max + counts[r]] for r in range(world)], dim=0)
+
+
+def draw_latent_shard(rows: int, dim: int, device, base_seed: int, rank: int, latent_distribution: str = "gaussian",
+                      latent_scale: float = 1.0) -> torch.Tensor:
+    """This rank's [rows x dim] latent block, drawn in place from its own generator seeded `base_seed + rank`: no rank
+    draws - or holds - another rank's block.  Same distributions as the reference's draw_latent (ikflow_solver.py:16-29)."""
+    assert latent_distribution in ("gaussian", "uniform")
+    g = torch.Generator(device=device)
+    g.manual_seed(int(base_seed) + int(rank))
+    if latent_distribution == "gaussian":
+        return latent_scale * torch.randn((rows, dim), generator=g, device=device)
+    return 2 * latent_scale * torch.rand((rows, dim), generator=g, device=device) - latent_scale
+
+
+def sharded_generate_ik_solutions_from_shard(solver, poses_shard: torch.Tensor, latent_shard: Optional[torch.Tensor] = None, *,
+                                             base_seed: int = 0, counts: Optional[Sequence[int]] = None, gather: bool = True,
+                                             group=None, **kw):
+    """generate_ik_solutions where every rank passes ONLY its own pose block (rank order = row order of the gathered result).
+    `latent_shard` None: drawn in place from `base_seed + rank`.  Returns the full [n x ndof] on every rank (`gather=False`: this
+    rank's block alone - no collective at all)."""
+    rank = dist.get_rank(group)
+    if latent_shard is None:
+        latent_shard = draw_latent_shard(poses_shard.shape[0], solver.network_width, poses_shard.device, base_seed, rank,
+                                         kw.get("latent_distribution", "gaussian"), kw.get("latent_scale", 1.0))
+    if poses_shard.shape[0] == 0:   # (a rank without rows still takes part in the collective)
+        ndof = getattr(solver, "ndof", None) or getattr(getattr(solver, "robot", None), "ndof", None) or latent_shard.shape[1]
+        local = torch.empty((0, int(ndof)), dtype=torch.float32, device=poses_shard.device)
+    else:
+        local = solver.generate_ik_solutions(poses_shard, n=(1 if poses_shard.shape[0] == 1 else None), latent=latent_shard, **kw)
+    return gather_blocks(local, group, counts) if gather else local
+
+
+def sharded_generate_exact_ik_solutions_from_shard(solver, poses_shard: torch.Tensor, *, counts: Optional[Sequence[int]] = None,
+                                                   group=None, **kw):
+    """generate_exact_ik_solutions on this rank's own pose block; solutions and valid flags of every rank in one collective."""
+    sol, valid = solver.generate_exact_ik_solutions(poses_shard, **kw)
+    full = gather_blocks(torch.cat([sol, valid.to(sol.dtype)[:, None]], dim=1), group, counts)
+    return full[:, :-1].contiguous(), full[:, -1] > 0.5
+
+
+class ShardedStepper:
+    """Repeated steps over a fixed shard: one step = `compute()` on this rank's row block, then the path's one collective -
+    all_gather_into_tensor of the [rows x cols] result into a preallocated, double-buffered [world * rows x cols] tensor.  On the GPU the
+    gather runs on its own stream behind an event, so the gather of step i overlaps the flow of step i + 1; `fence()` drains both streams
+    and barriers.  On CPU tensors (gloo) the same calls run inline.  `sync_before_gather`: gloo with device tensors only (tests) - gloo's
+    host staging does not reliably wait for the stream it is issued on."""
+
+    def __init__(self, compute: Callable[[], torch.Tensor], world: int, rank: int, rows: int, cols: int, device, use_dist: bool,
+                 n_buf: int = 2, sync_before_gather: bool = False, group=None):
+        self.compute, self.world, self.rank, self.rows, self.device, self.use_dist = compute, world, rank, rows, device, use_dist
+        self.group, self.sync_before_gather = group, sync_before_gather
+        self.cuda = torch.device(device).type == "cuda"
+        self.n_buf = n_buf
+        self.i = 0
+        self.keep = [None] * n_buf
+        self.gathered = [torch.empty((world * rows, cols), dtype=torch.float32, device=device) for _ in range(n_buf)] if use_dist else None
+        self.comm_stream = torch.cuda.Stream(device) if (use_dist and self.cuda) else None
+
+    def step(self) -> torch.Tensor:
+        sol = self.compute()
+        if self.use_dist:
+            k = self.i % self.n_buf
+            self.i += 1
+            if self.comm_stream is not None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                self.comm_stream.wait_event(ev)
+                if self.sync_before_gather:
+                    ev.synchronize()
+                with torch.cuda.stream(self.comm_stream):
+                    dist.all_gather_into_tensor(self.gathered[k], sol, group=self.group)
+                sol.record_stream(self.comm_stream)
+            else:
+                dist.all_gather_into_tensor(self.gathered[k], sol, group=self.group)
+            self.keep[k] = sol
+        return sol
+
+    def fence(self) -> None:
+        if self.use_dist:
+            if self.comm_stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            dist.barrier(group=self.group)
+        if self.cuda:
+            torch.cuda.synchronize(self.device)
+
+    def last_gathered(self) -> Optional[torch.Tensor]:
+        return self.gathered[(self.i - 1) % self.n_buf] if self.use_dist else None
 
 
 def sharded_rows(

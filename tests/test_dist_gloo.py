@@ -158,6 +158,72 @@ def _worker_solver(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
+def _worker_from_shard(rank, world, port, n, q):
+    from ikflow_amd.dist import (ShardedStepper, draw_latent_shard, gather_blocks, sharded_generate_exact_ik_solutions_from_shard,
+                                 sharded_generate_ik_solutions_from_shard)
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # every rank holds ONLY its own block, of a size only it knows (rank r: n + 3 r rows; n = 0: rank 0 has nothing at all)
+        rows = [n + 3 * r for r in range(world)]
+        blocks = [torch.randn(rows[r], 7, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]   # (the expectation only)
+        mine = blocks[rank]
+        s = _FakeSolver()
+        s.ndof = 7
+        base = 77
+        lat = [draw_latent_shard(rows[r], 7, "cpu", base, r) for r in range(world)]
+        want = torch.cat([torch.tanh(blocks[r]) + 0.5 * lat[r] for r in range(world)], dim=0)
+        got = sharded_generate_ik_solutions_from_shard(s, mine, base_seed=base)                     # sizes exchanged
+        ok = bool(torch.equal(got, want))
+        got = sharded_generate_ik_solutions_from_shard(s, mine, base_seed=base, counts=rows)       # sizes known: one collective
+        ok = ok and bool(torch.equal(got, want))
+        given = torch.full((rows[rank], 7), float(rank))
+        got = sharded_generate_ik_solutions_from_shard(s, mine, given, counts=rows)
+        ok = ok and bool(torch.equal(got, torch.cat([torch.tanh(blocks[r]) + 0.5 * torch.full((rows[r], 7), float(r)) for r in range(world)], dim=0)))
+        local = sharded_generate_ik_solutions_from_shard(s, mine, base_seed=base, gather=False)
+        ok = ok and bool(torch.equal(local, torch.tanh(mine) + 0.5 * lat[rank]))
+        # no two ranks draw the same block, and a rank's block does not depend on the world size
+        ok = ok and all(not torch.equal(lat[0][: min(rows)], lat[r][: min(rows)]) for r in range(1, world) if min(rows) > 0)
+        if all(r > 0 for r in rows):
+            sol, valid = sharded_generate_exact_ik_solutions_from_shard(s, mine)
+            ws, wv = s.generate_exact_ik_solutions(torch.cat(blocks, dim=0))
+            ok = ok and bool(torch.equal(sol, ws)) and bool(torch.equal(valid, wv)) and valid.dtype == torch.bool
+        ok = ok and bool(torch.equal(gather_blocks(mine), torch.cat(blocks, dim=0)))
+        # the stepper: equal shards, the gather double buffered
+        B = 5
+        shard = torch.randn(B, 7, generator=torch.Generator().manual_seed(rank))
+        st = ShardedStepper(lambda: torch.tanh(shard), world, rank, B, 7, "cpu", True)
+        for _ in range(3):
+            sol = st.step()
+        st.fence()
+        full = st.last_gathered()
+        ok = ok and bool(torch.equal(full[rank * B : (rank + 1) * B], sol))
+        ok = ok and all(bool(torch.equal(full[r * B : (r + 1) * B], torch.tanh(torch.randn(B, 7, generator=torch.Generator().manual_seed(r))))) for r in range(world))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1001), (3, 64), (3, 0)])
+def test_shard_in_forms_gloo(world, n):
+    """SURVEY 8(e) "Determinism: per-rank seeds = base_seed + rank, generated in place": the shard-in entry points take a rank's OWN block
+    (sizes exchanged or given; a rank may have no rows), draw its latents in place, and gather in rank order - nothing of size O(n) is
+    replicated but the result.  ShardedStepper (what bench.py steps through) gathers equal shards double-buffered."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_from_shard, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 @pytest.mark.parametrize("world,n", [(2, 1001), (3, 64)])
 def test_sharded_solver_entry_points_gloo(world, n):
     ctx = mp.get_context("spawn")
@@ -218,6 +284,16 @@ def _worker_real_solver(rank, world, port, n, q, backend="gloo"):
 
             pe, re = pose_errors(robot.forward_kinematics(sol[valid]), poses[valid])
             ok.append(float(pe.max()) <= 5e-3 and float(re.max()) <= 0.1)
+        # the shard-in form on the device: this rank's own block only, latents drawn in place from base_seed + rank
+        from ikflow_amd.dist import draw_latent_shard, shard_bounds, sharded_generate_ik_solutions_from_shard
+
+        lo, hi = shard_bounds(n, world, rank)
+        got = sharded_generate_ik_solutions_from_shard(s, poses[lo:hi].contiguous(), base_seed=31)
+        blocks = []
+        for r in range(world):
+            l, h = shard_bounds(n, world, r)
+            blocks.append(s.generate_ik_solutions(poses[l:h].contiguous(), latent=draw_latent_shard(h - l, lay.dim, dev, 31, r)))
+        ok.append(got.shape == (n, robot.ndof) and close(got, torch.cat(blocks, dim=0)))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
