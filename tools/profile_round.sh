@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the committed profile artifacts of a round on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r04      -> gpurun_out/prof_r04/{bench_kernel_stats.csv,pmc_summary.json,bench_default.json,...}
+#   tools/profile_round.sh r05      -> gpurun_out/prof_r04/{bench_kernel_stats.csv,pmc_summary.json,bench_default.json,...}
 # Copy the files you want judged into profiles/ afterwards (gpurun_out/ is scratch).
 # Every PMC pass is its own run with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$R
 mkdir -p "$OUT"
@@ -14,14 +14,14 @@ SQSET="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAI
 # kernel-trace statistics: the default workload (B = 4096: the row-owner launch), the same batch on the per-layer kernels, and the other cells
 # (200 steps: behind every idle gap the chip needs ~10 launches / 30 ms to come back to its clock - tools/launch_timing_check.py -
 # and a run has three such gaps; with 200 steps they stay a percent of the row-owner launch's average)
-for V in "default:" "per_layer:--gemm-variant 180" "b512:--batch 512" "b128:--batch 128" "f16x3:--precision f16x3"; do
+for V in "default:" "per_layer:--gemm-variant 180" "b512:--batch 512" "b128:--batch 128" "f16x3:--precision f16x3" "fetcharm8192:--model fetch_arm__large__mh186_9.25m --batch 8192"; do
   TAG=${V%%:*}; FLAGS=${V#*:}
   rocprofv3 --kernel-trace --stats -d /tmp/kt_${R}_$TAG -o kt --output-format csv -- python $REPO/bench.py --steps 200 --warmup 10 $COMMON $FLAGS > "$OUT/kt_$TAG.log" 2>&1
   NAME=bench_${TAG}_kernel_stats.csv; [ "$TAG" = default ] && NAME=bench_kernel_stats.csv
   cp "$(find /tmp/kt_${R}_$TAG -name '*kernel_stats.csv' | head -1)" "$OUT/$NAME"
 done
 # counters: FETCH_SIZE | WRITE_SIZE | SQ set, per regime, each pass a separate run
-for V in "default::k_flow_rowowner" "per_layer:--gemm-variant 180:k_flow_gemm" "b512:--batch 512:k_flow_cluster" "b128:--batch 128:k_flow_cluster" "b16:--batch 16:k_flow_cluster" "f16x3:--precision f16x3:k_split_gemm"; do
+for V in "default::k_flow_rowowner" "per_layer:--gemm-variant 180:k_flow_gemm" "b512:--batch 512:k_flow_cluster" "b128:--batch 128:k_flow_cluster" "b16:--batch 16:k_flow_cluster" "f16x3:--precision f16x3:k_split_gemm" "fetcharm8192:--model fetch_arm__large__mh186_9.25m --batch 8192:k_flow_rowowner"; do
   TAG=${V%%:*}; REST=${V#*:}; FLAGS=${REST%%:*}; KERN=${REST#*:}
   i=0; FILES=""
   for C in "FETCH_SIZE" "WRITE_SIZE" "$SQSET"; do
