@@ -882,6 +882,12 @@ static const float* chain_hi(const ikf_model* m) {
   return reinterpret_cast<const float*>(reinterpret_cast<const char*>(m->d_chain) + offsetof(Chain, hi));
 }
 
+// the small-batch tile configurations take their W fragments straight from the fragment-major image (narrow models pick them for
+// larger batches too: the choice goes by tile count, not by rows)
+static bool cfg_reads_frag_image(int cfg) {
+  return cfg == fused_skinny_cfg() || cfg == fused_skinny32_cfg() || cfg == fused_skinny16_cfg() || cfg == fused_skinny16x16_cfg() ||
+         cfg == fused_skinny32v2_cfg();
+}
 // fragment-major image of hidden layer l of subnet si, or null (not built for this width / not loaded)
 static const float* frag_image(const ikf_model* m, int si, int l) {
   const size_t i = (size_t)si * 3 + l;
@@ -1006,7 +1012,8 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   const FlowDims& d = m->dims;
   const int NB = m->desc.nb_nodes;
   const long long rows_pad = m->chunk_rows;
-  if (!m->wfrag_built && (nr <= 512 || m->tile_cfg >= 0)) {   // first small chunk on this path since the weights were loaded (or ikf_reserve did it)
+  if (!m->wfrag_built && (chain_usable(m, nr) || cfg_reads_frag_image((m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(nr, d.width, m->tune)))) {
+    // the first chunk on this path that reads the fragment-major image since the weights were loaded (or ikf_reserve built it already)
     ikf_status fst = build_frag_weights(m);
     if (fst != IKF_OK) return fst;
   }
@@ -1794,7 +1801,7 @@ extern "C" ikf_status ikf_time_gemm(ikf_model* m, int64_t rows, int iters, float
   hipStream_t s = static_cast<hipStream_t>(stream);
   st = ensure_scratch(m, rows);
   if (st != IKF_OK) return st;
-  if (rows <= 512 || m->tile_cfg >= 0) {
+  if (cfg_reads_frag_image((m->tile_cfg >= 0) ? m->tile_cfg : fused_pick_cfg(rows, m->dims.width, m->tune))) {
     st = build_frag_weights(m);
     if (st != IKF_OK) return st;
   }
