@@ -316,6 +316,47 @@ def flow_inverse_f64(sd: Dict, layout, latent: np.ndarray, conditional: np.ndarr
     return (x - b) @ np.asarray(sd["module_list.0.M_inv"], dtype=np.float64)
 
 
+def flow_forward_f64(sd: Dict, layout, x: np.ndarray, conditional: np.ndarray) -> np.ndarray:
+    """The graph in its FORWARD (training) direction, float64: [n x D] joint-space rows (padded to D) -> [n x D] latent.  The hot path never
+    runs it (ikflow_solver.py:98 calls rev=True only); it is here because a flow is a bijection - forward(inverse(z; c); c) = z is a
+    size-independent property the tests check at BASELINE.json's full batch sizes without a second run of the inverse.  Node order as built by
+    ikflow/model.py:300-354: FixedLinearTransform (x.mm(M) + b, the in-tree twin's forward branch model.py:214-218), then per block i = 0 .. N-1
+    PermuteRandom(seed=i) (x[:, perm]) and GLOWCouplingBlock forward [RECALLED, FrEIA 0.2]: r2 = subnet2([x2, c]), y1 = exp(clamp 0.636 atan(s2)) x1 + t2;
+    r1 = subnet1([y1, c]), y2 = exp(clamp 0.636 atan(s1)) x2 + t1 - the algebraic inverse of flow_inverse_* above, written independently."""
+    lay = OracleLayout.of(layout)
+    assert not lay.sigmoid_on_output, "forward of the sigmoid graph is not needed by any test"
+    L1, L2 = lay.len1, lay.len2
+    clamp = np.float64(np.float32(lay.clamp))
+    gain = np.float64(np.float32(GLOW_ATAN_GAIN))
+    slope = np.float64(np.float32(LEAKY_SLOPE))
+
+    def subnet(block, which, u):
+        base = f"module_list.{lay.glow_module(block)}.subnet{which}."
+        h = u
+        for layer in range(lay.n_hidden + 1):
+            h = h @ np.asarray(sd[f"{base}{2 * layer}.weight"], dtype=np.float64).T + np.asarray(sd[f"{base}{2 * layer}.bias"], dtype=np.float64)
+            if layer != lay.n_hidden:
+                h = np.where(h > 0, h, slope * h)
+        return h
+
+    c = np.asarray(conditional, dtype=np.float64)
+    b = np.asarray(sd["module_list.0.b"], dtype=np.float64) if "module_list.0.b" in sd else 0.0
+    M = np.asarray(sd["module_list.0.M"], dtype=np.float64) if "module_list.0.M" in sd else np.linalg.inv(np.asarray(sd["module_list.0.M_inv"], dtype=np.float64))
+    v = np.asarray(x, dtype=np.float64) @ M + b
+    for i in range(lay.nb_nodes):
+        perm_inv = np.asarray(sd[f"module_list.{lay.perm_module(i)}.perm_inv"], dtype=np.int64)
+        perm = np.empty_like(perm_inv)
+        perm[perm_inv] = np.arange(perm_inv.shape[0])      # (perm_inv[perm[k]] = k)
+        v = v[:, perm]
+        x1, x2 = v[:, :L1], v[:, L1:]
+        r2 = subnet(i, 2, np.concatenate([x2, c], 1))
+        y1 = np.exp(clamp * (gain * np.arctan(r2[:, :L1]))) * x1 + r2[:, L1:]
+        r1 = subnet(i, 1, np.concatenate([y1, c], 1))
+        y2 = np.exp(clamp * (gain * np.arctan(r1[:, :L2]))) * x2 + r1[:, L2:]
+        v = np.concatenate([y1, y2], 1)
+    return v
+
+
 def run_inference_f64(sd, layout, limits, latent, conditional, clamp_to_joint_limits: bool) -> np.ndarray:
     lay = OracleLayout.of(layout)
     out = flow_inverse_f64(sd, lay, latent, conditional)[:, : lay.ndof]

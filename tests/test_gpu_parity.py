@@ -11,7 +11,7 @@ import time
 import pytest
 import torch
 
-from helpers import O, custom_model, fetch_arm_model, latents, panda_model, reachable_poses, tiny_model
+from helpers import O, custom_model, fetch_arm_model, latents, panda_model, reachable_poses, released_model, tiny_model
 from ikflow_amd.ikflow_solver import IKFlowSolver
 from oracle import flow_oracle as fo
 from oracle import kinematics_oracle as ko
@@ -247,6 +247,31 @@ def test_full_batch_properties_4096():
     lo_t = torch.tensor([l[0] for l in O(robot).actuated_joints_limits], device=DEV)
     hi_t = torch.tensor([l[1] for l in O(robot).actuated_joints_limits], device=DEV)
     assert bool(((full >= lo_t) & (full <= hi_t)).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_name,n", [("panda__full__lp191_5.25m", 4096), ("panda__full__lp191_5.25m", 512), ("fetch__large__ns183_9.75m", 8192)])
+def test_round_trip_through_the_forward_pass_at_the_baseline_batch_sizes(model_name, n):
+    """Size-independent property at full size: the flow is a bijection, so the graph run FORWARD in fp64 on the host
+    (oracle/flow_oracle.py::flow_forward_f64, written independently of every inverse pass) must bring EVERY row of the HIP path's unclamped
+    output back to its latent - 4096 rows of the Panda model through the one row-owner launch, 512 through the cluster form, 8192 rows of the
+    16-block Fetch model (D = ndof = 8; FetchArm's 7 of 10 output columns cannot be inverted) through two rounds.  No second inverse pass is
+    involved, so an error shared by the kernels and the oracle's inverse would show here; coupling coefficients of O(1) (last Linear x 2)."""
+    robot, hp, lay, sd = released_model(model_name, seed=11, gain=2.0)
+    assert lay.dim == lay.ndof
+    s = _solver(robot, hp, sd)
+    _, poses = reachable_poses(robot, n, 71)
+    z = latents(n, lay.dim, 72)
+    x = s.generate_ik_solutions(poses.to(DEV), latent=z.to(DEV), clamp_to_joint_limits=False).cpu().numpy()
+    cond = torch.cat([poses, torch.zeros(n, 1)], 1).numpy()
+    back = fo.flow_forward_f64(sd, lay, x, cond)
+    err = np.abs(back - z.numpy()) / np.maximum(1.0, np.abs(z.numpy()))
+    # the oracle's own fp32 inverse on a slice sets the scale: what an fp32 inverse pass leaves after an exact forward pass
+    k = 256
+    ref = fo.flow_inverse_torch(sd, lay, z[:k], torch.tensor(cond[:k])).numpy()
+    ref_err = np.abs(fo.flow_forward_f64(sd, lay, ref, cond[:k]) - z[:k].numpy()) / np.maximum(1.0, np.abs(z[:k].numpy()))
+    assert err.max() <= 2e-5 and err.max() <= 4.0 * max(ref_err.max(), 1e-6), (float(err.max()), float(ref_err.max()))
+    assert np.median(err) <= 2.0 * max(np.median(ref_err), 1e-7), (float(np.median(err)), float(np.median(ref_err)))
 
 
 @pytest.mark.parametrize("which,n", [("panda", 4096), ("fetch_arm", 8192)])

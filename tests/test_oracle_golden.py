@@ -305,3 +305,28 @@ def test_generate_ik_solutions_restatement_equals_the_reference_statements():
     for name, kw in cases.items():
         with pytest.raises(AssertionError):
             s.generate_ik_solutions(**kw)
+
+
+def test_forward_pass_of_the_flow_inverts_the_inverse_pass():
+    """A flow is a bijection: the graph run forward (oracle/flow_oracle.py::flow_forward_f64 - written independently of the inverse) brings the
+    inverse pass's output back to the latent, for the released split (D = 7: 3 | 4), an odd / even mix of blocks, coupling coefficients
+    of O(1), with and without a non-zero softflow entry.  fp64 -> fp64 to the rounding of the fp32-stored M / M_inv pair; fp32 inverse -> fp64
+    forward to the inverse's own fp32 rounding.  The GPU test checks the same property at BASELINE.json's full batch size."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import custom_model, latents, reachable_poses, tiny_model
+
+    for make in (tiny_model, lambda: custom_model(nb_nodes=5, dim=7, n_hidden=3, width=96, gain=3.0),
+                 lambda: custom_model(nb_nodes=2, dim=10, n_hidden=2, width=64, robot_name="fetch_arm", gain=2.0)):
+        robot, hp, lay, sd = make()
+        n = 48
+        _, poses = reachable_poses(robot, n, 3)
+        z = latents(n, lay.dim, 4)
+        cond = torch.cat([poses, torch.zeros(n, 1)], 1)
+        cond[n // 2:, 7] = 0.3
+        x64 = fo.flow_inverse_f64(sd, lay, z.numpy(), cond.numpy())
+        assert np.abs(fo.flow_forward_f64(sd, lay, x64, cond.numpy()) - z.numpy()).max() <= 5e-7
+        x32 = fo.flow_inverse_torch(sd, lay, z, cond).numpy()
+        assert np.abs(fo.flow_forward_f64(sd, lay, x32, cond.numpy()) - z.numpy()).max() <= 2e-5
+        # (not an identity in disguise: another conditional does not bring the latent back)
+        assert np.abs(fo.flow_forward_f64(sd, lay, x64, np.roll(cond.numpy(), 1, axis=0)) - z.numpy()).max() >= 1e-3
