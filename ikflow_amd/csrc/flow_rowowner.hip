@@ -331,7 +331,23 @@ __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getr
 // stays spread (0.34 against 0.28 ms at 128 rows) and G = 2 gains nothing.  NOTHING is assumed: a census at load (cluster_placement_census),
 // and in every launch a member publishes its XCC_ID in the top byte of every epoch word; a consumer that meets another XCD's id gives up
 // (abort word, host word = 2) BEFORE it reads a payload, the repair launch recomputes the rows, and the handle goes back to the spread form.
-template <int G, bool LOCAL>
+// TAG (r05): the hand-over without a drain, an epoch word or a poll of one - every exchanged float carries the subnet's parity in the LEAST
+// significant bit of its mantissa (<= 1 ulp; every member works with the same tagged values, so the forms still agree member for member).
+// The producer stores and goes on; a consumer reads the payload itself and re-reads what still shows the other parity: stale data of the
+// previous subnet always does (a member can never be two subnets ahead of a reader, see the buffer-reuse argument above), and between
+// calls every float of the exchange buffers has parity 1 (n_sub is even; the buffers are created as 0xff bytes and re-created after an
+// aborted launch).  Needs nothing but the atomicity of a 4-byte store.
+__device__ __forceinline__ ro_f4 ro_tag(ro_f4 v, unsigned par) {
+  ro_u4 b = __builtin_bit_cast(ro_u4, v);
+  b = (b & ~1u) | par;
+  return __builtin_bit_cast(ro_f4, b);
+}
+__device__ __forceinline__ float ro_tag1(float v, unsigned par) { return __uint_as_float((__float_as_uint(v) & ~1u) | par); }
+__device__ __forceinline__ unsigned ro_tag_bad(ro_f4 v, unsigned par) {
+  const ro_u4 b = __builtin_bit_cast(ro_u4, v);
+  return ((b[0] ^ par) | (b[1] ^ par) | (b[2] ^ par) | (b[3] ^ par)) & 1u;
+}
+template <int G, bool LOCAL, bool TAG = false>
 __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   constexpr int NBM = RO_KG / G;                     // 16-column blocks of one member's slice (= 16-k groups of its k range)
   constexpr int KS = NBM >= RO_WAVES ? 1 : RO_WAVES / NBM;   // G >= 16: fewer blocks than waves - KS waves split the k range of a block
@@ -358,6 +374,9 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   const int j = LOCAL ? (int)(blockIdx.x / 8) % G : (int)blockIdx.x % G;
   const int rt = LOCAL ? (int)(blockIdx.x % 8) + 8 * ((int)(blockIdx.x / 8) / G) : (int)blockIdx.x / G;
   if (LOCAL && rt >= c.n_rt) return;   // (the grid is padded to whole groups of 8 row tiles; uniform per workgroup, nobody waits for these)
+  // (TAG) an earlier launch on these buffers gave up: they may hold the wrong parity, and nothing re-creates them until the host has seen it -
+  // this launch leaves everything to the repair launch queued behind it (the abort word is still set)
+  if (TAG && __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   constexpr int ST_AUX = LOCAL ? 0 : 16;   // payload stores: write-back into the shared L2 / write-through (sc1)
   const unsigned my_xcc = LOCAL ? ro_xcc_id() : 0u;
   const unsigned pub_xcc = my_xcc ^ ((LOCAL && c.test_far != 0 && blockIdx.x == 0) ? 1u : 0u);   // (tests: workgroup 0 claims to sit elsewhere)
@@ -526,6 +545,55 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   // [m CS, (m + 1) CS)).  One address register for the loads and one for the LDS writes; the rest is a scalar offset per load and an
   // immediate per write (a per-load index computation is loop-invariant, gets hoisted out of the subnet loop and costs two registers per
   // load for the whole kernel).  All loads of a thread (<= 8) are in flight together.
+  // (TAG) the same gather as below, re-read until every float shows parity `par`; false: the re-reads ran out / somebody aborted
+  auto gather_tagged = [&](const __amdgpu_buffer_rsrc_t& rsX, float* tile, unsigned par) -> bool {
+    constexpr int TH = RO_WAVES * 64;
+    constexpr int PEER4 = RO_ROWS * CS / 4;
+    constexpr int C4 = CS / 4;
+    constexpr int PPR = PEER4 >= TH ? 1 : TH / PEER4;
+    constexpr int RPP = PEER4 >= TH ? PEER4 / TH : 1;
+    constexpr int ROWS_PR = TH / PPR / C4;
+    constexpr int NLD = PPR == 1 ? (G - 1) * RPP : G / PPR;
+    static_assert(NLD <= 8, "all loads of a gather in flight together");
+    const int hw = PPR == 1 ? 0 : wave / (RO_WAVES / PPR);
+    const int tt = PPR == 1 ? t : (t & (TH / PPR - 1));
+    const int row_t = tt / C4, c4 = tt % C4;
+    const unsigned voffx = (unsigned)((row_t * RO_W + c4 * 4) * 4);
+    float* const tdst = tile + row_t * RO_LDA + c4 * 4 + hw * (NLD * CS);
+    ro_f4 v[NLD];
+    unsigned tries = 0, ok = 1;
+    for (;;) {
+      unsigned bad = 0;
+#pragma unroll
+      for (int r = 0; r < NLD; ++r) {
+        const int mq = 1 + r / RPP, rr = r % RPP;
+        const int m = mq + hw * NLD;
+        const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((rr * ROWS_PR * RO_W + ((j + m) & (G - 1)) * CS) * 4);
+        if (m < G) v[r] = __builtin_bit_cast(ro_f4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voffx, so, /*sc1*/ 16));
+      }
+#pragma unroll
+      for (int r = 0; r < NLD; ++r)
+        if (1 + r / RPP + hw * NLD < G) bad |= ro_tag_bad(v[r], par);
+      if (!__any(bad != 0)) break;
+      if ((++tries & 15u) == 0 && (tries > (kClusterSpinLimit >> 2) || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok && lane == 0) {
+      __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tries > (kClusterSpinLimit >> 2)) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      s_ok = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < NLD; ++r) {
+      const int mq = 1 + r / RPP, rr = r % RPP;
+      if (mq + hw * NLD < G) *reinterpret_cast<ro_f4*>(tdst + rr * ROWS_PR * RO_LDA + mq * CS) = v[r];
+    }
+    ro_barrier();
+    return s_ok != 0;
+  };
   auto gather = [&](const __amdgpu_buffer_rsrc_t& rsX, float* tile) {
     constexpr int TH = RO_WAVES * 64;
     constexpr int PEER4 = RO_ROWS * CS / 4;                     // float4 of one peer's slice: 2048 / 1024 / 512 / 256 / 128
@@ -570,6 +638,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       ro_f4 v_ = acc[cb_];                                                                                               \
       if constexpr (TWO) v_ += accb[cb_];                                                                                \
       v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
+      if (TAG && (PUB)) v_ = ro_tag(v_, tag_par);                                                                        \
       const int col_ = (int)(cbg0 + cb_) * 16 + 4 * lq;                                                                  \
       *reinterpret_cast<ro_f4*>((tile_out) + lrow * RO_LDA + (bw + cb_) * 16 + 4 * lq) = v_;                             \
       if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((lrow * RO_W + col_) * 4), 0, ST_AUX); \
@@ -583,6 +652,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       _Pragma("unroll") for (int k_ = 1; k_ < KS; ++k_)                                                                  \
           v_ += *reinterpret_cast<const ro_f4*>(red + (k_ * NBM + b_) * (RO_ROWS * RO_RS) + r_ * RO_RS + 4 * q_);        \
       v_ = __builtin_elementwise_max(v_, v_ * a.slope);                                                                  \
+      if (TAG && (PUB)) v_ = ro_tag(v_, tag_par);                                                                        \
       *reinterpret_cast<ro_f4*>((tile_out) + r_ * RO_LDA + b_ * 16 + 4 * q_) = v_;                                       \
       if (PUB) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ro_u4, v_), rsX, (unsigned)((r_ * RO_W + (j * NBM + b_) * 16 + 4 * q_) * 4), 0, ST_AUX); \
     }                                                                                                                    \
@@ -600,8 +670,12 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     if (!(WAIT && WAIT_AT == 0)) af[0] = RC_AFRAG(tile_in, 0);                                                           \
     _Pragma("unroll") for (int i_ = 0; i_ < KGW; ++i_) {                                                                 \
       if (WAIT && i_ == WAIT_AT) {                                                                                       \
-        if (!wait_peers(e_in)) return;                                                                                   \
-        gather(rsXin, tile_in);                                                                                          \
+        if constexpr (TAG) {                                                                                             \
+          if (!gather_tagged(rsXin, tile_in, tag_par)) return;                                                           \
+        } else {                                                                                                         \
+          if (!wait_peers(e_in)) return;                                                                                 \
+          gather(rsXin, tile_in);                                                                                        \
+        }                                                                                                                \
         af[i_ & 1] = RC_AFRAG(tile_in, i_);                                                                              \
       }                                                                                                                  \
       RC_ISSUE((i_ + PF) % NBUF, (hl_) + ((i_ + PF) / KGW), (i_ + PF) % KGW)                                             \
@@ -621,6 +695,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   for (int s = 0; s < a.n_sub; ++s) {
     const float* sm = small + s * RO_SMALL_WORDS;
     const unsigned e0 = (unsigned)s;   // epochs of this subnet's two exchanges: 2 s + 1 (h2), 2 s + 2 (partial sums)
+    const unsigned tag_par = (unsigned)s & 1u;   // (TAG) parity carried by everything this subnet exchanges
     RC_STAMP(1 + (s < 31 ? s : 31))
 #define RC_PHASE(i) if (s == 2) { RC_STAMP(40 + (i)) }
     RC_PHASE(0)
@@ -650,7 +725,8 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     // ---- hidden 2: tile0 (h1, complete) -> own columns of tile1 and X, epoch s + 1
     RC_LAYER(2 * s, b2, tile0, rsX1, 0u, false)
     RC_EPILOGUE(tile1, true, rsX1)
-    RC_PUBLISH(2 * e0 + 1)
+    if constexpr (TAG) ro_barrier();   // (own slice in LDS for every wave; nobody waits for the stores)
+    else RC_PUBLISH(2 * e0 + 1)
     RC_PHASE(2)
     // ---- hidden 3: tile1 (h2) -> own columns of tile0 (h3 stays here)
     RC_LAYER(2 * s + 1, b3, tile1, rsX1, 2 * e0 + 1, true)
@@ -679,11 +755,44 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
         const int row = t >> 4, o = t & 15;
 #pragma unroll
         for (int w = 0; w < RO_WAVES; ++w) mine += red[w * (RO_ROWS * RO_RS) + row * RO_RS + o];
+        if constexpr (TAG) mine = ro_tag1(mine, tag_par);
         if constexpr (LOCAL) P[j * 256 + t] = mine;
         else __hip_atomic_store(P + j * 256 + t, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      RC_PUBLISH(2 * e0 + 2)
+      if constexpr (!TAG) RC_PUBLISH(2 * e0 + 2)
       RC_FIRST_STATIC   // the next subnet's first Linear, state-independent half, under the exchange's latency (w1 = its weights by now)
+      if constexpr (TAG) {
+        // every member's partial, re-read until all of them show this subnet's parity (the own one is in `mine` already)
+        if (t < 256) {
+          const int row = t >> 4, o = t & 15;
+          float part[G];
+          unsigned tries = 0, ok = 1;
+          for (;;) {
+            unsigned bad = 0;
+#pragma unroll
+            for (int q = 0; q < G; ++q) part[q] = __hip_atomic_load(P + q * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int q = 0; q < G; ++q) bad |= (q == j) ? 0u : ((__float_as_uint(part[q]) ^ tag_par) & 1u);
+            if (!__any(bad != 0)) break;
+            if ((++tries & 15u) == 0 && (tries > (kClusterSpinLimit >> 2) || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+              ok = 0;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!ok && lane == 0) {
+            __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tries > (kClusterSpinLimit >> 2)) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_ok = 0;
+          }
+          float sum = sm[o];   // b_last (zero beyond n_out)
+#pragma unroll
+          for (int q = 0; q < G; ++q) sum += (q == j) ? mine : part[q];
+          s_sum[row * RO_RS + o] = sum;
+        }
+        ro_barrier();
+        if (s_ok == 0) return;
+      } else {
       if (!wait_peers(2 * e0 + 2)) return;
       if (t < 256) {
         const int row = t >> 4, o = t & 15;
@@ -702,6 +811,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
         s_sum[row * RO_RS + o] = sum;
       }
       ro_barrier();
+      }
     }
     RC_PHASE(4)
     advance(sm, s + 1 < a.n_sub ? sm + RO_SMALL_WORDS : nullptr, xs + 256 * xcur, xs + 256 * (xcur ^ 1));
@@ -831,6 +941,32 @@ hipError_t cluster_placement_census(int n_cu, bool* groups_of_8_share_an_xcd) {
   for (int b = 0; b < n_cu; ++b) ok = ok && h[b] <= 0xfu && h[b] == h[b % 8];
   *groups_of_8_share_an_xcd = ok;
   return hipSuccess;
+}
+// TAG variant: nothing is zeroed per launch - the exchange buffers are 0xff bytes when created (cluster_tagged_init) and hold parity 1
+// everywhere at the end of every call; the abort word stays 0 until a launch gives up (the engine then re-creates the buffers)
+template <int G, bool LOCAL>
+static hipError_t launch_cluster_tagged_g(const RcArgs& c, unsigned grid, hipStream_t s) {
+  static bool done[64] = {};
+  hipError_t e = ensure_dynamic_lds(k_flow_cluster<G, LOCAL, true>, RO_LDS_BYTES, done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_flow_cluster<G, LOCAL, true>), dim3(grid), dim3(RO_WAVES * 64), RO_LDS_BYTES, s, c);
+  return hipGetLastError();
+}
+hipError_t cluster_tagged_init(float* xbuf, size_t xbuf_floats, float* sync, size_t sync_bytes, unsigned* abort_word, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(xbuf, 0xff, xbuf_floats * sizeof(float), s);
+  if (e == hipSuccess) e = hipMemsetAsync(sync, 0xff, sync_bytes, s);
+  if (e == hipSuccess) e = hipMemsetAsync(abort_word, 0, sizeof(unsigned), s);
+  return e;
+}
+hipError_t launch_flow_cluster_tagged(const RcArgs& c, int G, hipStream_t s, int drop_workgroups, bool local) {
+  local = local && (G == 4 || G == 8 || G == 16) && drop_workgroups <= 0;
+  const unsigned grid = (local ? (unsigned)((c.n_rt + 7) / 8 * 8 * G) : (unsigned)c.n_rt * (unsigned)G) - (unsigned)(drop_workgroups > 0 ? 1 : 0);
+  if (G == 2) return launch_cluster_tagged_g<2, false>(c, grid, s);
+  if (G == 4) return local ? launch_cluster_tagged_g<4, true>(c, grid, s) : launch_cluster_tagged_g<4, false>(c, grid, s);
+  if (G == 8) return local ? launch_cluster_tagged_g<8, true>(c, grid, s) : launch_cluster_tagged_g<8, false>(c, grid, s);
+  if (G == 16) return local ? launch_cluster_tagged_g<16, true>(c, grid, s) : launch_cluster_tagged_g<16, false>(c, grid, s);
+  if (G == 32) return launch_cluster_tagged_g<32, false>(c, grid, s);
+  return hipErrorInvalidValue;
 }
 bool cluster_local_form(int G) { return G == 4 || G == 8 || G == 16; }   // (G = 2 gains nothing, G = 32 is bound by its weight stream: they stay spread)
 unsigned cluster_grid(int n_rt, int G, bool local) { return local ? (unsigned)((n_rt + 7) / 8 * 8 * G) : (unsigned)n_rt * (unsigned)G; }

@@ -112,6 +112,18 @@ struct ikf_model {
   long long cl_rows = 0;          // row capacity of the exchange buffers
   float* cl_xbuf = nullptr;       // [tiles][16][1024]
   float* cl_sync = nullptr;       // partial sums, epoch words, abort word (one memset per launch)
+  // The drain-free hand-over (r05, flow_rowowner.hip TAG): every exchanged float carries its subnet's parity in the last mantissa bit, so a
+  // producer neither drains its stores nor publishes an epoch and a consumer validates what it reads.  Taken for G = 2 .. 16 (- 3 .. 4.5 %
+  // per call, and no memset in front of the launch; with 32 members the early re-reads of whole slices cost more than the epoch words).
+  // Its buffers are its own: every float in them has parity 1 between calls (created as 0xff bytes; n_sub is even), which an epoch-word
+  // launch's zeroing memset or untagged payload would break.  cl_tag_dirty: a tagged launch gave up - the buffers are re-created in front of
+  // the next one (until then every tagged launch returns at once and its repair launch does the work: the abort word stays set).
+  //   cl_tagged: 1 (default) / 0 (ikf_set_gemm_variant 193 / 192)
+  int cl_tagged = 1;
+  float* cl_xbuf_t = nullptr;
+  float* cl_sync_t = nullptr;
+  size_t cl_sync_t_bytes = 0;
+  bool cl_tag_dirty = false;
   int* h_cl_give_up = nullptr;    // pinned, device-visible
   int cl_drop_next = 0;           // tests: the next cluster launch runs one workgroup short (ikf_set_gemm_variant 188): its tile's waits run out
   long long cl_repairs = 0;       // give-ups seen so far (ikf_cluster_repairs)
@@ -346,6 +358,8 @@ extern "C" void ikf_destroy(ikf_model* m) {
   if (m->d_ro_sub) (void)hipFree(m->d_ro_sub);
   if (m->cl_xbuf) (void)hipFree(m->cl_xbuf);
   if (m->cl_sync) (void)hipFree(m->cl_sync);
+  if (m->cl_xbuf_t) (void)hipFree(m->cl_xbuf_t);
+  if (m->cl_sync_t) (void)hipFree(m->cl_sync_t);
   if (m->h_cl_give_up) (void)hipHostFree(m->h_cl_give_up);
   if (m->d_perm_inv) (void)hipFree(m->d_perm_inv);
   if (m->d_Minv) (void)hipFree(m->d_Minv);
@@ -799,6 +813,10 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     m->wt_stores = variant == 134 ? -1 : variant - 130;
     return IKF_OK;
   }
+  if (variant == 192 || variant == 193) {  // cluster form, G = 2 .. 16: hand-over by epoch words / by parity-tagged payload (default)
+    m->cl_tagged = variant - 192;
+    return IKF_OK;
+  }
   if (variant == 191) {  // tests of the placement check: the next XCD-local cluster launch is told that workgroup 0 sits on another XCD
     m->cl_far_next = 1;
     return IKF_OK;
@@ -855,7 +873,7 @@ extern "C" ikf_status ikf_set_gemm_variant(ikf_model* m, int variant) {
     return IKF_OK;
   }
   if (variant < -1 || variant >= gemm_variant_count())
-    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused by batch size, 101..108 fused with tile configuration 0..7, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on, 158 / 159 16 x 16 tiles for <= 64 rows off / on, 160 / 161 / 164 small-batch tile configurations 9 / 10 / 11 forced, 162 / 163 configuration 11 for 129..256 rows off / on, 170 / 171 one-launch subnet chain for <= 128 rows off / on, 180 / 181 / 182 row-owner launch never / by plan / always, 185 / 186 / 187 cluster form never / by plan / whenever the grid fits, 188 / 191 tests of its repair paths, 189 / 190 its members spread / on one XCD; see include/ikflow_amd_debug.h)");
+    return fail(IKF_ERR_BAD_ARGUMENT, "unknown gemm variant (-1 auto, 0..N-1 unfused tile shapes, 100 fused by batch size, 101..108 fused with tile configuration 0..7, 110 / 111 / 112 one-launch small-batch form off / auto / forced, 120 / 121 in-launch entry phase off / on, 130..134 write-through activation stores none / contractions / entry / both / by batch size, 150 / 151 16-row tiles for <= 128 rows off / on, 152 / 153 their whole-stream prefetch off / on, 158 / 159 16 x 16 tiles for <= 64 rows off / on, 160 / 161 / 164 small-batch tile configurations 9 / 10 / 11 forced, 162 / 163 configuration 11 for 129..256 rows off / on, 170 / 171 one-launch subnet chain for <= 128 rows off / on, 180 / 181 / 182 row-owner launch never / by plan / always, 185 / 186 / 187 cluster form never / by plan / whenever the grid fits, 188 / 191 tests of its repair paths, 189 / 190 its members spread / on one XCD, 192 / 193 its hand-over by epoch words / tagged payload; see include/ikflow_amd_debug.h)");
   m->gemm_variant = variant;
   m->tile_cfg = -1;
   return IKF_OK;
@@ -1183,7 +1201,7 @@ static ikf_status run_flow_chunk_unfused(ikf_model* m, const PoseSource& ps, con
 // whatever part of it is used) and the cluster form (G = 8 / 4 / 2: <= 512 / 1024 / 2048 rows at a fixed cost each).  A batch is cut into
 // consecutive chunks by the cheapest plan under the measured costs of the released 12-block shape on 256 CUs (ms per launch,
 // tools/rowowner_ab.py, profiles/r04_rowowner_ab.jsonl) - the ratios, not the absolute values, decide, and they hold for any depth:
-//   row-owner round 2.82;  cluster 0.285 / 0.36 / 0.51 / 0.84 / 1.55 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows);
+//   row-owner round 2.82;  cluster 0.285 / 0.335 / 0.485 / 0.82 / 1.51 for G = 32 / 16 / 8 / 4 / 2 (<= 128 / 256 / 512 / 1024 / 2048 rows; r05);
 //   per-layer 0.272 / 0.305 / 0.316 / 0.367 / 0.52 / 0.71 / 1.04 / 1.75 / 2.56 / 2.62 / 3.20 up to 1 / 16 / 64 / 128 / 256 / 512 / 1024 /
 //   2048 / 2560 / 3072 / 4096 rows (+ 0.10 beside the resident-row forms: another weight image, see plan_tail);  + 0.01 per extra chunk.
 // e.g. 1 .. 128 -> cluster 32; 200 -> cluster 16; 512 -> cluster 8; 600 -> cluster 4; 1536 -> cluster 4 (1024) + cluster 8 (512); 2304 -> cluster 2 (2048) + per-layer (256);
@@ -1206,6 +1224,7 @@ static void cluster_fold_give_up(ikf_model* m) {
   *m->h_cl_give_up = 0;
   ++m->cl_repairs;
   m->cl_clean = 0;
+  m->cl_tag_dirty = true;                        // (whichever hand-over it was: the tagged buffers are re-created before their next use)
   if (why == 2) m->cl_local = 0;                 // a member of the XCD-local form met a peer on another XCD: back to the spread form
   else {                                         // a wait ran out: somebody else held CUs - sit out, twice as long as the last time
     m->cl_backoff = m->cl_backoff == 0 ? kClusterFirstPause : (m->cl_backoff * 2 < kClusterMaxPause ? m->cl_backoff * 2 : kClusterMaxPause);
@@ -1256,7 +1275,7 @@ static const TailPlan& plan_tail(long long rows, long long round, bool ro, bool 
     best = TailPlan{per_layer_cost(on256) + ((mixed || cl) ? 0.10 : 0.0), {{0, rows}}};
     if (ro && 2.82 < best.cost) best = TailPlan{2.82, {{1, rows}}};
     if (cl) {
-      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.36}, {8, 0.51}, {4, 0.84}, {2, 1.55}};
+      static const struct { int G; double ms; } forms[] = {{32, 0.285}, {16, 0.335}, {8, 0.485}, {4, 0.82}, {2, 1.51}};   // (r05: tagged hand-over for G <= 16)
       for (const auto& f : forms) {
         const long long cap = (round / IKF_RO_ROWS) / f.G * IKF_RO_ROWS;   // rows of a full grid of this form: whole tiles, at most one workgroup per CU
         if (cap <= 0) continue;
@@ -1362,11 +1381,18 @@ static ikf_status ensure_cluster_scratch(ikf_model* m, long long rows) {
   if (rows <= m->cl_rows) return IKF_OK;
   if (m->cl_xbuf) (void)hipFree(m->cl_xbuf);
   if (m->cl_sync) (void)hipFree(m->cl_sync);
-  m->cl_xbuf = nullptr; m->cl_sync = nullptr; m->cl_rows = 0;
+  if (m->cl_xbuf_t) (void)hipFree(m->cl_xbuf_t);
+  if (m->cl_sync_t) (void)hipFree(m->cl_sync_t);
+  m->cl_xbuf = nullptr; m->cl_sync = nullptr; m->cl_xbuf_t = nullptr; m->cl_sync_t = nullptr; m->cl_rows = 0;
   const long long cap = (long long)m->n_cu / 2 * IKF_RO_ROWS;   // the largest chunk the form takes (G = 2)
   const int tiles = (int)((cap + IKF_RO_ROWS - 1) / IKF_RO_ROWS);
   IKF_HIP(hipMalloc(&m->cl_xbuf, sizeof(float) * cluster_xbuf_floats(tiles)));
   IKF_HIP(hipMalloc(&m->cl_sync, cluster_sync_bytes(tiles, 8)));   // (sized for G = 8 on every tile: 4.6 KB per tile)
+  // the tagged hand-over's own pair (same sizes; its abort word is the block's LAST word, wherever a launch's partial sums end)
+  m->cl_sync_t_bytes = cluster_sync_bytes(tiles, 8);
+  IKF_HIP(hipMalloc(&m->cl_xbuf_t, sizeof(float) * cluster_xbuf_floats(tiles)));
+  IKF_HIP(hipMalloc(&m->cl_sync_t, m->cl_sync_t_bytes));
+  m->cl_tag_dirty = true;   // (created by the first launch that uses them, on its stream)
   m->cl_rows = cap;
   return IKF_OK;
 }
@@ -1377,16 +1403,32 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
   RcArgs c{};
   c.ro = rowowner_args(m, ps, d_latent, r0, nr, clamp_limits, d_q_out);
   c.n_rt = (int)((nr + IKF_RO_ROWS - 1) / IKF_RO_ROWS);
-  c.xbuf = m->cl_xbuf;
-  c.pbuf = m->cl_sync;
-  c.flags = reinterpret_cast<unsigned*>(m->cl_sync) + (size_t)c.n_rt * G * 256;
-  c.abort_word = c.flags + (size_t)c.n_rt * G * 32;
-  c.give_up = m->h_cl_give_up;
-  IKF_HIP(prof_mark(m, s));
+  const bool tagged = m->cl_tagged != 0 && G <= 16 && (2 * m->desc.nb_nodes) % 2 == 0;
   const bool local = m->cl_local != 0 && cluster_local_form(G) && cluster_grid(c.n_rt, G, true) <= (unsigned)m->n_cu;
-  c.test_far = local ? m->cl_far_next : 0;
-  if (local) m->cl_far_next = 0;
-  IKF_HIP(launch_flow_cluster(c, G, s, m->cl_drop_next, local));
+  c.give_up = m->h_cl_give_up;
+  if (tagged) {
+    unsigned* const abort_t = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(m->cl_sync_t) + m->cl_sync_t_bytes - 128);
+    if (m->cl_tag_dirty) {
+      IKF_HIP(cluster_tagged_init(m->cl_xbuf_t, cluster_xbuf_floats((int)(m->cl_rows / IKF_RO_ROWS)), m->cl_sync_t, m->cl_sync_t_bytes - 128, abort_t, s));
+      m->cl_tag_dirty = false;
+    }
+    c.xbuf = m->cl_xbuf_t;
+    c.pbuf = m->cl_sync_t;
+    c.flags = nullptr;
+    c.abort_word = abort_t;
+    c.test_far = 0;
+    IKF_HIP(prof_mark(m, s));
+    IKF_HIP(launch_flow_cluster_tagged(c, G, s, m->cl_drop_next, local));
+  } else {
+    c.xbuf = m->cl_xbuf;
+    c.pbuf = m->cl_sync;
+    c.flags = reinterpret_cast<unsigned*>(m->cl_sync) + (size_t)c.n_rt * G * 256;
+    c.abort_word = c.flags + (size_t)c.n_rt * G * 32;
+    c.test_far = local ? m->cl_far_next : 0;
+    if (local) m->cl_far_next = 0;
+    IKF_HIP(prof_mark(m, s));
+    IKF_HIP(launch_flow_cluster(c, G, s, m->cl_drop_next, local));
+  }
   m->cl_drop_next = 0;
   IKF_HIP(prof_mark(m, s));
   // the repair launch: the same rows through the row-owner kernel, which returns at once unless a wait of the cluster launch ran out

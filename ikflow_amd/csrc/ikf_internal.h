@@ -245,6 +245,9 @@ struct RcArgs {            // cluster form (k_flow_cluster<G>): G workgroups per
 size_t cluster_xbuf_floats(int n_rt);
 size_t cluster_sync_bytes(int n_rt, int G);   // pbuf + flags + the abort word
 hipError_t launch_flow_cluster(const RcArgs& c, int G, hipStream_t s, int drop_workgroups = 0, bool local = false);
+// the drain-free hand-over (every exchanged float carries the subnet's parity in its mantissa's last bit): buffers initialised once
+hipError_t cluster_tagged_init(float* xbuf, size_t xbuf_floats, float* sync, size_t sync_bytes, unsigned* abort_word, hipStream_t s);
+hipError_t launch_flow_cluster_tagged(const RcArgs& c, int G, hipStream_t s, int drop_workgroups = 0, bool local = false);
 hipError_t cluster_placement_census(int n_cu, bool* groups_of_8_share_an_xcd);   // one tiny launch: where workgroup b of a grid lands
 bool cluster_local_form(int G);                          // G = 4 / 8 / 16: a form with every member of a row tile on one XCD exists
 unsigned cluster_grid(int n_rt, int G, bool local);      // workgroups of a launch (the local form pads to whole groups of 8 row tiles)

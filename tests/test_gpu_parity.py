@@ -1661,6 +1661,67 @@ def test_cluster_form_is_tried_again_after_a_pause_that_doubles():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [130, 256, 300, 512, 1000, 1024, 1536, 2048, 2600])
+def test_cluster_form_tagged_hand_over_against_epoch_words_and_the_oracle(n):
+    """The default hand-over of the cluster form with 2 .. 16 members (r05): every exchanged float carries its subnet's parity in the last
+    mantissa bit - no drain, no epoch word, no memset in front of the launch; a consumer re-reads what still shows the other parity.  The
+    tag moves an activation by at most one ulp, so the two hand-overs agree to rounding (not bit for bit), each is reproducible bit for bit,
+    both sit inside the tolerance against the oracle at coupling coefficients of O(1), and XCD-local and spread placement still give the
+    same bits (same tagged values, another memory path)."""
+    robot, hp, lay, sd = panda_model(gain=2.0)
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    _, poses = reachable_poses(robot, n, 141)
+    lat = latents(n, lay.dim, 142)
+    P, L = poses.to(DEV), lat.to(DEV)
+    tagged = [s.generate_ik_solutions(P, latent=L, clamp_to_joint_limits=False).clone() for _ in range(4)]
+    eng.set_gemm_variant(189)
+    tagged_spread = s.generate_ik_solutions(P, latent=L, clamp_to_joint_limits=False).clone()
+    eng.set_gemm_variant(190)
+    eng.set_gemm_variant(192)
+    words = s.generate_ik_solutions(P, latent=L, clamp_to_joint_limits=False).clone()
+    eng.set_gemm_variant(193)
+    tagged.append(s.generate_ik_solutions(P, latent=L, clamp_to_joint_limits=False).clone())
+    torch.cuda.synchronize()
+    assert all(torch.equal(tagged[0], t) for t in tagged[1:]) and torch.equal(tagged[0], tagged_spread)
+    scale = torch.clamp(words.abs(), min=1.0)
+    assert ((tagged[0] - words).abs() / scale).max().item() <= 8e-6   # (an ulp on an activation, carried through 24 subnets at gain 2)
+    ref = torch.tensor(fo.flow_inverse_f64(sd, lay, lat.numpy(), torch.cat([poses, torch.zeros(n, 1)], 1).numpy())[:, : lay.ndof])
+    for got in (tagged[0], words):
+        assert ((got.cpu().double() - ref).abs() / torch.clamp(ref.abs(), min=1.0)).max().item() <= FLOW_TOL
+    assert eng.cluster_repairs == 0
+
+
+@pytest.mark.gpu
+def test_cluster_form_tagged_buffers_after_a_give_up_with_calls_already_queued():
+    """The tagged hand-over keeps an invariant between calls - every float of its exchange buffers has parity 1 - that a launch which gave up
+    breaks.  The host only learns of a give-up when it plans a later call, so launches may already be queued behind the broken one: each of
+    them finds the abort word still set, returns at once and leaves its rows to its own repair launch; the first call planned after the host
+    has seen the give-up re-creates the buffers.  Here: one launch a workgroup short, five more calls queued behind it without a
+    synchronisation, every result inside the tolerance, and after the pause the form is back with its own bits."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    sets = []
+    for k, n in enumerate((512, 300, 1024, 512, 2048, 200)):
+        _, poses = reachable_poses(robot, n, 150 + k)
+        sets.append((poses.to(DEV), latents(n, lay.dim, 160 + k).to(DEV)))
+    good = [s.generate_ik_solutions(P, latent=L).clone() for P, L in sets]
+    torch.cuda.synchronize()
+    eng.set_gemm_variant(188)
+    outs = [s.generate_ik_solutions(P, latent=L).clone() for P, L in sets]     # no synchronisation in between
+    torch.cuda.synchronize()
+    for g, o in zip(good, outs):
+        assert (g - o).abs().max().item() <= FLOW_TOL
+    assert eng.cluster_repairs == 1 and eng.cluster_backoff > 0
+    while eng.cluster_backoff > 0:
+        s.generate_ik_solutions(*sets[0][:1], latent=sets[0][1])
+    again = [s.generate_ik_solutions(P, latent=L).clone() for P, L in sets]
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, g) for a, g in zip(again, good)) and eng.cluster_repairs == 1
+
+
+@pytest.mark.gpu
 def test_small_batch_weight_image_is_built_on_first_use_only():
     """The fragment-major image of the small-batch per-layer kernels (+ 201 MB for Panda, 48 pack launches) is no longer part of
     ikf_load_weights: a handle whose small batches run the cluster form never builds it; the first <= 512-row chunk that does take the
@@ -1737,6 +1798,7 @@ def test_cluster_form_xcd_local_placement_check_falls_back_to_the_spread_form():
     eng.set_gemm_variant(182)
     ro = s.generate_ik_solutions(P, latent=L).clone()
     eng.set_gemm_variant(181)
+    eng.set_gemm_variant(192)   # the epoch-word hand-over: the tagged one (default) validates the payload itself and publishes no ids
     good = s.generate_ik_solutions(P, latent=L).clone()
     assert eng.cluster_repairs == 0 and eng.cluster_local
     eng.set_gemm_variant(191)

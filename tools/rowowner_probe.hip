@@ -101,7 +101,7 @@ int main(int argc, char** argv) {
   float *d_x = up(hx), *d_p = up(hp), *d_Minv = up(Minv), *d_blin = up(blin), *d_lo = up(lo), *d_hi = up(hi), *d_q;
   CK(hipMalloc(&d_q, (size_t)M * ndof * 4));
   const unsigned n_tiles = (M + RO_ROWS - 1) / RO_ROWS;
-  const unsigned grid = duo == 3 ? pair_grid((int)n_tiles, G) : (duo == 2 ? (n_tiles + 7) / 8 * 8 : n_tiles) * (unsigned)G;   // (the XCD-local form pads to whole groups of 8 row tiles)
+  const unsigned grid = duo == 3 ? pair_grid((int)n_tiles, G) : ((duo == 2 || (duo == 4 && (G == 4 || G == 8 || G == 16))) ? (n_tiles + 7) / 8 * 8 : n_tiles) * (unsigned)G;   // (the XCD-local form pads to whole groups of 8 row tiles)
   unsigned long long* d_trace; CK(hipMalloc(&d_trace, (size_t)grid * 64 * 8)); CK(hipMemset(d_trace, 0, (size_t)grid * 64 * 8));
   RoArgs a{};
   a.stream = d_stream; a.stream_bytes = (unsigned)(stream_floats * 4); a.sub = d_sub; a.n_sub = n_sub; a.x0 = d_x;
@@ -119,9 +119,11 @@ int main(int argc, char** argv) {
     rc.abort_word = rc.flags + (size_t)n_rtb * G * 32;
     CK(hipHostMalloc(&h_give_up, 4, hipHostMallocMapped)); *h_give_up = 0;
     rc.give_up = h_give_up;
+    if (duo == 4 || duo == 5)   // the tagged hand-over: buffers created as 0xff bytes, nothing zeroed per launch
+      CK(cluster_tagged_init(rc.xbuf, cluster_xbuf_floats(n_rt2), rc.pbuf, cluster_sync_bytes(n_rt2, G) - 128, rc.abort_word, nullptr));
   }
   auto launch = [&]() -> hipError_t {
-    if (G > 1) { rc.ro = a; return duo == 3 ? launch_flow_pair(rc, G, nullptr) : duo == 1 ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr, 0, /*local=*/duo == 2); }
+    if (G > 1) { rc.ro = a; if (duo == 4 || duo == 5) return launch_flow_cluster_tagged(rc, G, nullptr, 0, /*local=*/duo == 4); return duo == 3 ? launch_flow_pair(rc, G, nullptr) : duo == 1 ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr, 0, /*local=*/duo == 2); }
     return launch_flow_rowowner(a, nbuf, nullptr);
   };
 #define launch_flow_rowowner(a_, n_, s_) launch()
@@ -180,7 +182,7 @@ int main(int argc, char** argv) {
       max_err = std::max(max_err, fabs(q - (double)hq[(size_t)r * ndof + j]));
     }
   }
-  printf("%sG %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", duo == 3 ? "pair " : duo ? "duo " : "", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
+  printf("%sG %d rows %d blocks %d D %d nbuf %d: max |q - fp64 reference| over %zu rows = %.3g %s\n", duo == 3 ? "pair " : duo == 4 ? "tagged local " : duo == 5 ? "tagged spread " : duo ? "duo " : "", G, M, NB, D, nbuf, rows.size(), max_err, max_err < 2e-5 ? "OK" : "MISMATCH");
   // timing
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i) CK(launch_flow_rowowner(a, nbuf, nullptr));
