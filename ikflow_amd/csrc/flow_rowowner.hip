@@ -336,7 +336,10 @@ __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getr
 // The producer stores and goes on; a consumer reads the payload itself and re-reads what still shows the other parity: stale data of the
 // previous subnet always does (a member can never be two subnets ahead of a reader, see the buffer-reuse argument above), and between
 // calls every float of the exchange buffers has parity 1 (n_sub is even; the buffers are created as 0xff bytes and re-created after an
-// aborted launch).  Needs nothing but the atomicity of a 4-byte store.
+// aborted launch).  Needs nothing but the atomicity of a 4-byte store.  Measured (tools/rowowner_probe, modes 4 / 5 against 2 / 0): 512 rows
+// G = 8 47.3 k -> 45.6 k cycles per subnet, 1024 rows G = 4 79.8 -> 77.5 k, 256 rows G = 16 32.4 -> 31.2 k, 2048 rows G = 2 149.9 -> 145.4 k.
+// NOT for G = 32: a consumer's first read comes before its 31 peers are done and every re-read moves 64 KB per CU - 0.30 - 0.33 ms at 128
+// rows against 0.284 with epoch words, whatever delay precedes the first read.
 __device__ __forceinline__ ro_f4 ro_tag(ro_f4 v, unsigned par) {
   ro_u4 b = __builtin_bit_cast(ro_u4, v);
   b = (b & ~1u) | par;
@@ -765,29 +768,33 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
         // every member's partial, re-read until all of them show this subnet's parity (the own one is in `mine` already)
         if (t < 256) {
           const int row = t >> 4, o = t & 15;
-          float part[G];
+          constexpr int CH = G < 16 ? G : 16;   // loads in flight together
+          float sum = sm[o];   // b_last (zero beyond n_out)
           unsigned tries = 0, ok = 1;
-          for (;;) {
-            unsigned bad = 0;
 #pragma unroll
-            for (int q = 0; q < G; ++q) part[q] = __hip_atomic_load(P + q * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int mb = 0; mb < G; mb += CH) {
+            float part[CH];
+            for (;;) {
+              unsigned bad = 0;
 #pragma unroll
-            for (int q = 0; q < G; ++q) bad |= (q == j) ? 0u : ((__float_as_uint(part[q]) ^ tag_par) & 1u);
-            if (!__any(bad != 0)) break;
-            if ((++tries & 15u) == 0 && (tries > (kClusterSpinLimit >> 2) || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-              ok = 0;
-              break;
+              for (int q = 0; q < CH; ++q) part[q] = __hip_atomic_load(P + (mb + q) * 256 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+              for (int q = 0; q < CH; ++q) bad |= (mb + q == j) ? 0u : ((__float_as_uint(part[q]) ^ tag_par) & 1u);
+              if (!__any(bad != 0) || !ok) break;
+              if ((++tries & 15u) == 0 && (tries > (kClusterSpinLimit >> 2) || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                ok = 0;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) sum += (mb + q == j) ? mine : part[q];   // (member order)
           }
           if (!ok && lane == 0) {
             __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tries > (kClusterSpinLimit >> 2)) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_ok = 0;
           }
-          float sum = sm[o];   // b_last (zero beyond n_out)
-#pragma unroll
-          for (int q = 0; q < G; ++q) sum += (q == j) ? mine : part[q];
           s_sum[row * RO_RS + o] = sum;
         }
         ro_barrier();
