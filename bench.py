@@ -504,8 +504,14 @@ def cell_approx(solver, robot, layout, B, dev, reps, seed):
     q = torch.tensor(robot.sample_joint_angles(B, EPS_LIMITS, np.random.default_rng(seed)), device=dev)
     poses = robot.forward_kinematics(q)
     lat = torch.randn(B, layout.dim, generator=torch.Generator().manual_seed(seed)).to(dev)
-    for _ in range(5):
-        solver.generate_ik_solutions(poses, latent=lat)
+    # warm-up by TIME, not by count: the chip drops its clocks within ~10 ms of idling (the FK / randn above are such a gap) and needs ~30 ms of
+    # work to come back (tools/launch_timing_check.py); five 0.5 ms calls left a 512-row cell 5 % above its steady figure
+    torch.cuda.synchronize(dev)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.04:
+        for _ in range(5):
+            solver.generate_ik_solutions(poses, latent=lat)
+        torch.cuda.synchronize(dev)
     dt, _ = _sync_time(lambda: solver.generate_ik_solutions(poses, latent=lat), reps, dev)
     tf, fr = _frac(B / dt, layout)
     return {"ms_per_call": round(1e3 * dt, 4), "solutions_per_s": B / dt, "flow_rows_per_s": B / dt,

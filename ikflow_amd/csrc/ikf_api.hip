@@ -1403,7 +1403,7 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
   RcArgs c{};
   c.ro = rowowner_args(m, ps, d_latent, r0, nr, clamp_limits, d_q_out);
   c.n_rt = (int)((nr + IKF_RO_ROWS - 1) / IKF_RO_ROWS);
-  const bool tagged = m->cl_tagged != 0 && G <= 16 && (2 * m->desc.nb_nodes) % 2 == 0;
+  const bool tagged = m->cl_tagged != 0 && G <= 16;   // (the parity argument needs an even number of subnets: 2 per coupling block)
   const bool local = m->cl_local != 0 && cluster_local_form(G) && cluster_grid(c.n_rt, G, true) <= (unsigned)m->n_cu;
   c.give_up = m->h_cl_give_up;
   if (tagged) {
