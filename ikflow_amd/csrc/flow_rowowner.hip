@@ -340,7 +340,8 @@ __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getr
 // G = 8 47.3 k -> 45.6 k cycles per subnet, 1024 rows G = 4 79.8 -> 77.5 k, 256 rows G = 16 32.4 -> 31.2 k, 2048 rows G = 2 149.9 -> 145.4 k.
 // Requesting the peers' slices EARLY (under the member's own k groups) returns nothing: a load reads L2 when it is REQUESTED, not when its data
 // comes back behind the weight ring, so a request made before the peers' stores have landed reads the old parity and the re-read costs what the
-// late request costs (45.5 k against 45.6 k cycles per subnet at 512 rows).
+// late request costs (45.5 k against 45.6 k cycles per subnet at 512 rows); requested half way through the own k groups: - 0.5 k of 77 k at G = 4,
+// - 0.5 k of 145 k at G = 2.
 // NOT for G = 32: a consumer's first read comes before its 31 peers are done and every re-read moves 64 KB per CU - 0.30 - 0.33 ms at 128
 // rows against 0.284 with epoch words, whatever delay precedes the first read.
 __device__ __forceinline__ ro_f4 ro_tag(ro_f4 v, unsigned par) {
