@@ -33,7 +33,10 @@ names) for coeff_fn_config 1..4 - tests/golden/ref_vectors.npz holds outputs of 
 ``IkFlowFixedLinearTransform.forward`` and ``InvertibleSigmoidFlipped.forward`` (ikflow/model.py:51-96, 120-146, 191-233,
 executed from the reference file by tests/golden/make_ref_vectors.py in the build container); the permutation tables (numpy legacy MT19937 literals); the Panda scale vector; the sigmoid scaling node's known answers
 (tests/model_test.py:50-123).  NOT pinned by any reference vector: the coupling arithmetic itself (split order, s|t order,
-0.636*atan clamp, perm_inv direction) - "parity unpinned", restated from FrEIA 0.2's published code.
+0.636*atan clamp, perm_inv direction) - "parity unpinned", restated from FrEIA 0.2's published code.  The pin for it is armed:
+tests/golden/make_ref_thirdparty.py + tests/test_thirdparty_pin.py compare this file with FrEIA's GraphINN itself wherever FrEIA==0.2 and
+jrl are importable (they are not in the build container).  Independent of any recall: ``flow_forward_f64`` runs the graph the other way, and
+forward(inverse(z)) = z is checked at full batch size on the GPU path (a flow is a bijection).
 """
 from __future__ import annotations
 

@@ -22,7 +22,8 @@ Restated jrl algorithm (published code of jrl/robot.py, jrl/math_utils.py):
 PARITY STATUS: pinned by the reference's tests ONLY at Panda FK(q=0) and the pi geodesic / L2 known answers
 (tests/evaluation_utils_test.py:18-32) and the Panda limits (tests/model_test.py:27-44) - all checked in
 tests/test_oracle_golden.py.  The LM step (row order, rpy parametrisation, lambda, alpha) and every FetchArm
-number are "parity unpinned": restated from memory of jrl's published code, no vector to check against.
+number are "parity unpinned": restated from memory of jrl's published code, no vector to check against - until jrl is importable:
+tests/test_thirdparty_pin.py then compares FK, the LM step, the geodesic distance, limits and clamp with jrl's own (armed, dormant here).
 """
 from __future__ import annotations
 
