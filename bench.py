@@ -77,10 +77,10 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------------
 def ShardedStepper(compute, world, rank, rows, cols, device, use_dist, n_buf=2):
     """The library form (ikflow_amd/dist.py::ShardedStepper): compute() on this rank's shard, the one all-gather per step on a side
-    stream, double buffered.  (tests only: gloo with device tensors drains the producer stream before its host staging.)"""
+    stream, double buffered."""
     from ikflow_amd.dist import ShardedStepper as _Stepper
 
-    return _Stepper(compute, world, rank, rows, cols, device, use_dist, n_buf=n_buf, sync_before_gather=(TEST_BACKEND == "gloo"))
+    return _Stepper(compute, world, rank, rows, cols, device, use_dist, n_buf=n_buf)
 
 
 def timed_steps(stepper, steps, warmup):
@@ -99,8 +99,6 @@ def timed_steps(stepper, steps, warmup):
         import torch.distributed as dist
 
         t = torch.tensor([elapsed], device=stepper.device, dtype=torch.float64)
-        if t.is_cuda and dist.get_backend() == "gloo":  # tests only: see collective_proof
-            torch.cuda.synchronize(t.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, sol
@@ -167,22 +165,14 @@ def collective_proof(stepper, sol, rank, world, local_rank, dev, affinity=None, 
     full = stepper.last_gathered()
     own = sol.contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
     sums = torch.empty(world, dtype=torch.int64, device=sol.device)
-
-    def drain():  # tests only (gloo with device tensors): its host staging does not reliably wait for the producer stream (ikflow_amd/dist.py)
-        if sol.is_cuda and dist.get_backend() == "gloo":
-            torch.cuda.synchronize(sol.device)
-
-    drain()
     dist.all_gather_into_tensor(sums, own)
     ok = bool(torch.equal(full[rank * B : (rank + 1) * B], sol))
     for r in range(world):
         ok = ok and int(full[r * B : (r + 1) * B].contiguous().view(torch.int32).to(torch.int64).sum().item()) == int(sums[r].item())
     flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=sol.device)
-    drain()
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     times = torch.empty(world, dtype=torch.float64, device=sol.device)
     mine_t = torch.tensor([stepper.local_elapsed], dtype=torch.float64, device=sol.device)
-    drain()
     dist.all_gather_into_tensor(times, mine_t)
     me = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
     if affinity is not None:
@@ -683,6 +673,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if TEST_BACKEND:  # tests only: every rank on cuda:0 of a one-GPU box, gloo instead of RCCL (RCCL refuses two ranks on one device)
             local_rank = 0
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import gloo_staging   # (test scaffolding: gloo is never handed a device tensor)
+
+            gloo_staging.install()
             dist.init_process_group(TEST_BACKEND)
         else:
             local_rank = device_index_for(rank, local_rank, torch.cuda.device_count())

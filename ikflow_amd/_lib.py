@@ -114,6 +114,8 @@ SIGNATURES = {
     "ikf_profile_event_overhead_ms": (C.c_double, [C.c_void_p]),
     "ikf_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "ikf_get_precision": (C.c_int, [C.c_void_p]),
+    "ikf_set_lm_precision": (C.c_int, [C.c_void_p, C.c_int]),
+    "ikf_get_lm_precision": (C.c_int, [C.c_void_p]),
     "ikf_set_split_guard": (C.c_int, [C.c_void_p, C.c_int]),
     "ikf_split_fallback_count": (C.c_int64, [C.c_void_p]),
     "ikf_split_overflow_pending": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -84,6 +84,7 @@ struct ikf_model {
   unsigned* d_arrive = nullptr;  // [kArriveWords] row-tile arrival counters of the fused tail (zeroed by every call's first entry kernel)
   int* h_give_up = nullptr;      // pinned, device-visible: set by a workgroup whose in-launch wait ran out
   int precision = 0;      // 0: hidden contractions on the exact-f32 MFMA; 1: error-compensated 3x f16 MFMA split
+  int lm_precision = 1;   // LM step: 1 fp64 inside (Cholesky), 0 the reference's fp32 arithmetic (LU, partial pivoting) - ikf_set_lm_precision
   uint16_t* split_arena = nullptr;  // split-32 images of the hidden Linear weights
   std::vector<const void*> w_mid_split;  // [subnet][layer] -> device pointer (flattened: subnet*3 + layer)
   float* split_frag_arena = nullptr;     // fragment-major copies of the split-32 images (small-batch f16-split kernel)
@@ -137,6 +138,7 @@ struct ikf_model {
   bool cl_used_last = false;      // the previous plan contained a cluster launch
   int cl_census_ok = -1;          // the placement census at load: workgroups b and b + 8 k share an XCD (1) or not (0); -1 not asked
   int cl_far_next = 0;            // tests (ikf_set_gemm_variant 191): the next XCD-local launch's workgroup 0 publishes a wrong XCC_ID
+  unsigned cl_launch_seq = 0;     // tagged + XCD-local launches carry a 24-bit sequence number in their placement words (RcArgs::launch_seq)
   int cl_local = 1;               // G = 4 / 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
                                   // peer on another XCD (placement is verified in the launch, never assumed) or by ikf_set_gemm_variant 189
 
@@ -155,6 +157,7 @@ struct ikf_model {
   float* xbuf = nullptr;     // [chunk][D]
   float* xbuf2 = nullptr;    // [chunk][D]   second state buffer (fused path ping-pongs the state)
   float* pbuf = nullptr;     // [slots][chunk][IKF_PSTRIDE] last-Linear partial sums (fused path)
+  float* pbuf_alt = nullptr; // second set for odd subnets when a subnet has ONE hidden contraction (see ensure_scratch); else == pbuf
   float* hA = nullptr;       // [chunk][width]
   float* hB = nullptr;
   // exact-IK scratch
@@ -254,7 +257,7 @@ static void free_scratch(ikf_model* m) {
   if (m->hB) (void)hipFree(m->hB);
   if (m->xbuf2) (void)hipFree(m->xbuf2);
   if (m->pbuf) (void)hipFree(m->pbuf);
-  m->xbuf = m->hA = m->hB = m->xbuf2 = m->pbuf = nullptr;
+  m->xbuf = m->hA = m->hB = m->xbuf2 = m->pbuf = m->pbuf_alt = nullptr;
   m->chunk_rows = 0;
   m->chain_tab_valid = false;  // (the table holds these pointers)
 }
@@ -729,7 +732,15 @@ static ikf_status ensure_scratch(ikf_model* m, long long rows) {
   IKF_HIP(hipMalloc(&m->hB, sizeof(float) * (size_t)want * m->dims.width));
   IKF_HIP(hipMalloc(&m->xbuf2, sizeof(float) * (size_t)want * m->dims.D));
   const size_t slots = (size_t)(fused_max_slots(m->dims.width) > 0 ? fused_max_slots(m->dims.width) : 1);
-  IKF_HIP(hipMalloc(&m->pbuf, sizeof(float) * slots * (size_t)want * IKF_PSTRIDE));
+  // With ONE hidden contraction per subnet (coeff_fn_config 2, e.g. TINY_MODEL_PARAMS) the one-launch subnet head (k_entry_gemm_skinny*) is
+  // also the subnet's LAST contraction: the same launch reads the previous subnet's partial sums (pending coupling, every slot of its row
+  // tile) and writes its own.  In one buffer that is a write-after-read hazard between the workgroups of a row tile - harmless only while all
+  // of them start together; when another process holds CUs a late workgroup read slots a finished sibling had already overwritten (r06: the
+  // red two-ranks-on-one-GPU test of round 5, tools/two_tenant_determinism.py).  Such shapes alternate between two sets by subnet parity.
+  const size_t pset = slots * (size_t)want * IKF_PSTRIDE;
+  const bool two_sets = m->dims.n_hidden == 2;
+  IKF_HIP(hipMalloc(&m->pbuf, sizeof(float) * pset * (two_sets ? 2 : 1)));
+  m->pbuf_alt = two_sets ? m->pbuf + pset : m->pbuf;
   m->chunk_rows = want;
   return IKF_OK;
 }
@@ -776,8 +787,10 @@ extern "C" ikf_status ikf_reserve(ikf_model* m, int64_t max_rows) {
   if (max_rows < 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_reserve: max_rows must be positive");
   IKF_ON_DEVICE(m)
   ikf_status st = ensure_scratch(m, max_rows);
-  // the small-batch per-layer kernels' weight image, if any call on this handle can reach them (otherwise the first such chunk builds it)
-  if (st == IKF_OK && m->loaded && !m->wfrag_built && !(rowowner_allowed_fwd(m) && cluster_allowed_now(m))) st = build_frag_weights(m);
+  // the small-batch per-layer kernels' weight image (201 MB at the released shape): also on a handle whose small batches normally take the
+  // cluster form - during a back-off pause (another process held CUs) they run these kernels, and that is the worst moment for a hipMalloc,
+  // 48 pack launches and a device-wide synchronisation inside a call
+  if (st == IKF_OK && m->loaded && !m->wfrag_built) st = build_frag_weights(m);
   return st;
 }
 
@@ -1065,6 +1078,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
   pend.P = nullptr;
   const float* x_src = d_latent + (size_t)r0 * d.D;
   float* xb[2] = {m->xbuf, m->xbuf2};
+  float* const pb[2] = {m->pbuf, m->pbuf_alt};   // partial sums of even / odd subnets (the same buffer unless a launch both reads and writes them)
   auto entry_args = [&](int sidx, const PendingCoupling& pc, const float* xs) {
     const int b = NB - 1 - sidx / 2, which = 1 + (sidx & 1);
     const SubnetWeights& w = m->subnets[2 * b + which - 1];
@@ -1089,7 +1103,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     g.M = (int)nr; g.N = d.width; g.K = d.width; g.slope = d.slope;
     g.wt_stores = m->wt_stores < 0 ? 1 : (m->wt_stores & 1);
     g.tune = m->tune;
-    g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = m->pbuf; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
+    g.w_last = w.w_last; g.n_out = w.n_out; g.P_out = pb[sidx & 1]; g.p_slot_stride = rows_pad * IKF_PSTRIDE;
     const int n_mid = d.n_hidden - 1;
     // small batches: the entry kernel and the first hidden contraction run as one launch (k_entry_gemm_skinny).  In the
     // chain it pays with the 32x32 tiles (129 .. 256 rows: 0.56 -> 0.53 ms per call) and the 16-row tiles (<= 128 rows, where it
@@ -1104,7 +1118,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
     entry_done = false;
     // the pending coupling this subnet leaves behind (its last Linear exists only as partial sums)
     PendingCoupling mine{};
-    mine.P = m->pbuf;
+    mine.P = pb[sidx & 1];
     mine.b_last = w.b_last;
     mine.perm_inv = m->d_perm_inv + (size_t)b * d.D;
     mine.slot_stride = rows_pad * IKF_PSTRIDE;
@@ -1121,7 +1135,7 @@ static ikf_status run_flow_chunk_fused(ikf_model* m, const PoseSource& ps, const
         sg.A = cur; sg.C = last ? nullptr : nxt; sg.W = m->w_mid_split[(size_t)(2 * b + which - 1) * 3 + l];
         sg.Wf = m->w_mid_split_frag.empty() ? nullptr : m->w_mid_split_frag[(size_t)(2 * b + which - 1) * 3 + l];
         sg.bias = w.b_mid[l]; sg.M = (int)nr; sg.N = d.width; sg.K = d.width; sg.slope = d.slope;
-        sg.w_last = w.w_last; sg.n_out = w.n_out; sg.P_out = m->pbuf; sg.p_slot_stride = rows_pad * IKF_PSTRIDE;
+        sg.w_last = w.w_last; sg.n_out = w.n_out; sg.P_out = pb[sidx & 1]; sg.p_slot_stride = rows_pad * IKF_PSTRIDE;
         sg.flag = m->d_split_flag;
         IKF_HIP(launch_split_gemm(last, scfg, sg, s));
       } else {
@@ -1416,7 +1430,13 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
     c.pbuf = m->cl_sync_t;
     c.flags = nullptr;
     c.abort_word = abort_t;
-    c.test_far = 0;
+    c.test_far = local ? m->cl_far_next : 0;   // (variant 191: honoured by the tagged form's placement check too)
+    if (local) m->cl_far_next = 0;
+    // the members' placement words sit behind the partial sums of the largest launch (the epoch-word form's flag area, unused here)
+    c.xcc_words = reinterpret_cast<unsigned*>(m->cl_sync_t) + (size_t)(m->cl_rows / IKF_RO_ROWS) * 8 * 256;
+    m->cl_launch_seq = (m->cl_launch_seq + 1) & 0xffffffu;
+    if (m->cl_launch_seq == 0xffffffu) m->cl_launch_seq = 0;
+    c.launch_seq = m->cl_launch_seq;
     IKF_HIP(prof_mark(m, s));
     IKF_HIP(launch_flow_cluster_tagged(c, G, s, m->cl_drop_next, local));
   } else {
@@ -1577,7 +1597,7 @@ extern "C" ikf_status ikf_lm_step(ikf_model* m, const float* d_target_poses, con
                                   void* stream) {
   IKF_KIN_PROLOGUE("ikf_lm_step")
   if (!d_q || !d_target_poses || !d_q_out) return fail(IKF_ERR_NULL_POINTER, "ikf_lm_step: null device pointer");
-  IKF_HIP(launch_lm_step(m->d_chain, m->dims.ndof, d_target_poses, d_q, n, d_q_out, s));
+  IKF_HIP(launch_lm_step(m->d_chain, m->dims.ndof, d_target_poses, d_q, n, d_q_out, m->lm_precision, s));
   return IKF_OK;
 }
 extern "C" ikf_status ikf_jacobian(ikf_model* m, const float* d_q, int64_t n, float* d_jac_out, void* stream) {
@@ -1759,7 +1779,7 @@ static ikf_status run_exact(ikf_model* m, const float* d_target_poses, int64_t n
     }
     // all LM iterations of the round in one launch + one selection (kin_kernels.hip: k_exact_lm_iters)
     IKF_HIP(launch_exact_lm_iters(m->d_chain, ndof, d_target_poses, m->ex_pose_idx, (int)n_active, R, n_lm_steps, d_q_seed, m->ex_q,
-                                  m->ex_row_valid, m->ex_pose_first, pos_thr, rot_thr, s));
+                                  m->ex_row_valid, m->ex_pose_first, pos_thr, rot_thr, m->lm_precision, s));
     IKF_HIP(launch_exact_select_first(ndof, m->ex_pose_idx, (int)n_active, R, m->ex_q, m->ex_row_valid, d_q_out, d_valid_out,
                                       r == 0 ? 1 : 0, s));
     if (h_stats) {
@@ -1938,6 +1958,13 @@ extern "C" ikf_status ikf_set_precision(ikf_model* m, int mode) {
   return IKF_OK;
 }
 extern "C" int ikf_get_precision(const ikf_model* m) { return m ? m->precision : -1; }
+extern "C" ikf_status ikf_set_lm_precision(ikf_model* m, int mode) {
+  if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_lm_precision: null model");
+  if (mode != 0 && mode != 1) return fail(IKF_ERR_BAD_ARGUMENT, "ikf_set_lm_precision: mode must be 0 (fp32, the reference's arithmetic) or 1 (fp64 inside the step)");
+  m->lm_precision = mode;
+  return IKF_OK;
+}
+extern "C" int ikf_get_lm_precision(const ikf_model* m) { return m ? m->lm_precision : -1; }
 
 extern "C" ikf_status ikf_set_split_guard(ikf_model* m, int guard) {
   if (!m) return fail(IKF_ERR_NULL_POINTER, "ikf_set_split_guard: null model");

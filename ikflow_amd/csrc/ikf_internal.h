@@ -239,6 +239,9 @@ struct RcArgs {            // cluster form (k_flow_cluster<G>): G workgroups per
   unsigned* abort_word;    // device word behind the flags (same memset): set when a wait ran out - every other wait ends, and the
                            // row-owner launch queued behind this one (run_if = abort_word) recomputes the chunk
   int test_far;            // tests: workgroup 0 of the XCD-local form publishes a wrong XCC_ID (its peers must give up with code 2)
+  unsigned* xcc_words;     // tagged + XCD-local form: [n_rt][G] words (launch_seq << 8 | XCC_ID), one per member, written at the start of every
+                           // launch; a member compares its peers' ids with its own BEFORE it reads a payload (a word outside the partial sums)
+  unsigned launch_seq;     // ... 24 bits, never 0xffffff (what the buffers are created as), another value in every launch
   int* give_up;            // host-visible twin: 1 = a wait ran out (the engine stops using the cluster form on this handle), 2 = a member
                            // of the XCD-local form met a peer on another XCD (the engine goes back to the spread form)
 };
@@ -332,8 +335,9 @@ hipError_t launch_self_collision(const Chain* d_chain, const CollisionModel* d_c
 hipError_t launch_fk(const Chain* d_chain, int ndof, const float* q, long long n, float* poses, hipStream_t s);
 hipError_t launch_pose_error(const Chain* d_chain, int ndof, const float* q, const float* targets, long long n,
                              float* pos_err, float* rot_err, hipStream_t s);
+// lm_precision: 1 = fp64 inside (default), 0 = the reference's fp32 arithmetic with an LU / partial-pivoting solve
 hipError_t launch_lm_step(const Chain* d_chain, int ndof, const float* targets, const float* q, long long n,
-                          float* q_out, hipStream_t s);
+                          float* q_out, int lm_precision, hipStream_t s);
 hipError_t launch_jacobian(const Chain* d_chain, int ndof, const float* q, long long n, float* jac, hipStream_t s);
 hipError_t launch_clamp(const Chain* d_chain, int ndof, const float* q, long long n, float* q_out, hipStream_t s);
 hipError_t launch_limits_exceeded(const Chain* d_chain, int ndof, const float* q, long long n, uint8_t* out,
@@ -349,7 +353,7 @@ hipError_t launch_limits_exceeded_table(const float* lo, const float* hi, int nc
 hipError_t launch_exact_lm_iters(const Chain* d_chain, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
                                  int n_steps, const float* q_in /* seeds; may be q */, float* q, uint8_t* row_valid_iter,
                                  unsigned* pose_first /* [n_active] scratch, or null: no early exit */, float pos_thr, float rot_thr,
-                                 hipStream_t s);
+                                 int lm_precision, hipStream_t s);
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,
                                      const uint8_t* row_valid_iter, float* q_out, uint8_t* valid_out, int init, hipStream_t s);
 hipError_t launch_all_active(long long n, int* idx_out, int* count_out, hipStream_t s);  // idx = 0 .. n-1, count = n (round 0)

@@ -149,62 +149,14 @@ __device__ __forceinline__ void pose_error_f32(const Chain* __restrict__ ch, con
   *rot_err = geodesic_f32(tq, pose + 3);
 }
 
-// One damped least-squares step in fp64: q <- clamp(q + (J^T J + 1e-4 I)^-1 J^T e)
+__device__ __forceinline__ float atan2_t(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, x); }
+__device__ __forceinline__ float asin_t(float a) { return asinf(a); }
+__device__ __forceinline__ double asin_t(double a) { return asin(a); }
+
+// Solve A x = g in place (x -> g), A symmetric positive definite, lower triangle filled: Cholesky A = L L^T (the fp64 mode)
 template <int NDOF>
-__device__ __forceinline__ void lm_step_row(const Chain* __restrict__ ch, const float* __restrict__ tgt,
-                                            float qv[NDOF]) {
-  double qd[NDOF];
-#pragma unroll
-  for (int j = 0; j < NDOF; ++j) qd[j] = (double)qv[j];
-  double R[9], p[3], axw[NDOF][3], orw[NDOF][3];
-  fk_walk<double, NDOF, true>(ch, qd, R, p, axw, orw);
-  double qc[4];
-  mat_to_quat<double>(R, qc);
-  // rotation error quaternion = q_target * conj(q_current), as roll/pitch/yaw
-  const double w1 = tgt[3], x1 = tgt[4], y1 = tgt[5], z1 = tgt[6];
-  const double w2 = qc[0], x2 = -qc[1], y2 = -qc[2], z2 = -qc[3];
-  const double ew = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
-  const double ex = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
-  const double ey = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
-  const double ez = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
-  double e[6];
-  e[0] = atan2(2.0 * (ew * ex + ey * ez), 1.0 - 2.0 * (ex * ex + ey * ey));
-  e[1] = asin(fmin(fmax(2.0 * (ew * ey - ez * ex), -1.0), 1.0));
-  e[2] = atan2(2.0 * (ew * ez + ex * ey), 1.0 - 2.0 * (ey * ey + ez * ez));
-  e[3] = (double)tgt[0] - p[0];
-  e[4] = (double)tgt[1] - p[1];
-  e[5] = (double)tgt[2] - p[2];
-  // Jacobian columns: revolute [axis; axis x (p_ee - origin)], prismatic [0; axis]
-  double J[6][NDOF];
-#pragma unroll
-  for (int j = 0; j < NDOF; ++j) {
-    if (ch->joints[j].kind == 1) {
-      const double rx = p[0] - orw[j][0], ry = p[1] - orw[j][1], rz = p[2] - orw[j][2];
-      J[0][j] = axw[j][0]; J[1][j] = axw[j][1]; J[2][j] = axw[j][2];
-      J[3][j] = axw[j][1] * rz - axw[j][2] * ry;
-      J[4][j] = axw[j][2] * rx - axw[j][0] * rz;
-      J[5][j] = axw[j][0] * ry - axw[j][1] * rx;
-    } else {
-      J[0][j] = J[1][j] = J[2][j] = 0.0;
-      J[3][j] = axw[j][0]; J[4][j] = axw[j][1]; J[5][j] = axw[j][2];
-    }
-  }
-  double A[NDOF][NDOF], g[NDOF];
-#pragma unroll
-  for (int a = 0; a < NDOF; ++a) {
-#pragma unroll
-    for (int b = 0; b <= a; ++b) {
-      double sacc = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) sacc += J[r][a] * J[r][b];
-      A[a][b] = sacc + (a == b ? 1e-4 : 0.0);
-    }
-    double gs = 0.0;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) gs += J[r][a] * e[r];
-    g[a] = gs;
-  }
-  // Cholesky A = L L^T (lower), in place; then forward/back substitution
+__device__ __forceinline__ void solve_cholesky(double A[NDOF][NDOF], double g[NDOF]) {
 #pragma unroll
   for (int c = 0; c < NDOF; ++c) {
     double dsum = A[c][c];
@@ -235,6 +187,113 @@ __device__ __forceinline__ void lm_step_row(const Chain* __restrict__ ch, const 
     for (int k = r + 1; k < NDOF; ++k) v -= A[k][r] * g[k];
     g[r] = v / A[r][r];
   }
+}
+
+// Solve A x = g in place (x -> g), A full: LU with partial pivoting, then the two triangular solves - what torch.linalg.solve does on the
+// reference's fp32 tensors (LAPACK sgesv = sgetrf + sgetrs; ikflow_solver.py:205,208 -> jrl).  Everything stays in registers: the pivot
+// row is found by an unrolled compare and the swap is an unrolled select, so no index is a run-time value.
+template <int NDOF>
+__device__ __forceinline__ void solve_lu_pivot(float A[NDOF][NDOF], float g[NDOF]) {
+#pragma unroll
+  for (int c = 0; c < NDOF; ++c) {
+    int piv = c;
+    float best = fabsf(A[c][c]);
+#pragma unroll
+    for (int r = c + 1; r < NDOF; ++r) {
+      const float v = fabsf(A[r][c]);
+      if (v > best) { best = v; piv = r; }   // (first maximum wins, as isamax)
+    }
+#pragma unroll
+    for (int r = c + 1; r < NDOF; ++r) {
+      const bool sw = piv == r;
+#pragma unroll
+      for (int k = 0; k < NDOF; ++k) {
+        const float a = A[c][k], b = A[r][k];
+        A[c][k] = sw ? b : a;
+        A[r][k] = sw ? a : b;
+      }
+      const float ga = g[c], gb = g[r];
+      g[c] = sw ? gb : ga;
+      g[r] = sw ? ga : gb;
+    }
+    const float inv = 1.0f / A[c][c];
+#pragma unroll
+    for (int r = c + 1; r < NDOF; ++r) {
+      const float l = A[r][c] * inv;
+#pragma unroll
+      for (int k = c + 1; k < NDOF; ++k) A[r][k] -= l * A[c][k];
+      g[r] -= l * g[c];   // (forward substitution with the unit lower factor, applied as the factor is formed)
+    }
+  }
+#pragma unroll
+  for (int r = NDOF - 1; r >= 0; --r) {
+    float v = g[r];
+#pragma unroll
+    for (int k = r + 1; k < NDOF; ++k) v -= A[r][k] * g[k];
+    g[r] = v / A[r][r];
+  }
+}
+
+// One damped least-squares step: q <- clamp(q + (J^T J + 1e-4 I)^-1 J^T e).
+//   T = double (default, lm_precision 1): chain walk, Jacobian, normal equations and a Cholesky solve in fp64, q rounded to fp32 at the end;
+//   T = float  (lm_precision 0): the reference's own arithmetic - every quantity fp32 (ikflow/config.py:8), LU with partial pivoting.
+template <int NDOF, typename T>
+__device__ __forceinline__ void lm_step_row(const Chain* __restrict__ ch, const float* __restrict__ tgt,
+                                            float qv[NDOF]) {
+  T qd[NDOF];
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) qd[j] = (T)qv[j];
+  T R[9], p[3], axw[NDOF][3], orw[NDOF][3];
+  fk_walk<T, NDOF, true>(ch, qd, R, p, axw, orw);
+  T qc[4];
+  mat_to_quat<T>(R, qc);
+  // rotation error quaternion = q_target * conj(q_current), as roll/pitch/yaw
+  const T w1 = tgt[3], x1 = tgt[4], y1 = tgt[5], z1 = tgt[6];
+  const T w2 = qc[0], x2 = -qc[1], y2 = -qc[2], z2 = -qc[3];
+  const T ew = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
+  const T ex = w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2;
+  const T ey = w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2;
+  const T ez = w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2;
+  T e[6];
+  e[0] = atan2_t((T)2 * (ew * ex + ey * ez), (T)1 - (T)2 * (ex * ex + ey * ey));
+  e[1] = asin_t(fmin(fmax((T)2 * (ew * ey - ez * ex), (T)-1), (T)1));
+  e[2] = atan2_t((T)2 * (ew * ez + ex * ey), (T)1 - (T)2 * (ey * ey + ez * ez));
+  e[3] = (T)tgt[0] - p[0];
+  e[4] = (T)tgt[1] - p[1];
+  e[5] = (T)tgt[2] - p[2];
+  // Jacobian columns: revolute [axis; axis x (p_ee - origin)], prismatic [0; axis]
+  T J[6][NDOF];
+#pragma unroll
+  for (int j = 0; j < NDOF; ++j) {
+    if (ch->joints[j].kind == 1) {
+      const T rx = p[0] - orw[j][0], ry = p[1] - orw[j][1], rz = p[2] - orw[j][2];
+      J[0][j] = axw[j][0]; J[1][j] = axw[j][1]; J[2][j] = axw[j][2];
+      J[3][j] = axw[j][1] * rz - axw[j][2] * ry;
+      J[4][j] = axw[j][2] * rx - axw[j][0] * rz;
+      J[5][j] = axw[j][0] * ry - axw[j][1] * rx;
+    } else {
+      J[0][j] = J[1][j] = J[2][j] = (T)0;
+      J[3][j] = axw[j][0]; J[4][j] = axw[j][1]; J[5][j] = axw[j][2];
+    }
+  }
+  T A[NDOF][NDOF], g[NDOF];
+#pragma unroll
+  for (int a = 0; a < NDOF; ++a) {
+#pragma unroll
+    for (int b = 0; b <= a; ++b) {
+      T sacc = (T)0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) sacc += J[r][a] * J[r][b];
+      A[a][b] = sacc + (a == b ? (T)1e-4 : (T)0);
+      A[b][a] = A[a][b];
+    }
+    T gs = (T)0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) gs += J[r][a] * e[r];
+    g[a] = gs;
+  }
+  if constexpr (sizeof(T) == 8) solve_cholesky<NDOF>(A, g);
+  else solve_lu_pivot<NDOF>(A, g);
 #pragma unroll
   for (int j = 0; j < NDOF; ++j) {
     const float qn = (float)(qd[j] + g[j]);
@@ -270,14 +329,14 @@ __global__ __launch_bounds__(256) void k_pose_error(const Chain* __restrict__ ch
   rot_err[row] = re;
 }
 
-template <int NDOF>
+template <int NDOF, typename T>
 __global__ __launch_bounds__(256) void k_lm_step(const Chain* __restrict__ ch, const float* __restrict__ tgt,
                                                  const float* __restrict__ q, long long n, float* __restrict__ q_out) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
   float qv[NDOF];
   load_q<NDOF>(q, row, qv);
-  lm_step_row<NDOF>(ch, tgt + (size_t)row * 7, qv);
+  lm_step_row<NDOF, T>(ch, tgt + (size_t)row * 7, qv);
 #pragma unroll
   for (int j = 0; j < NDOF; ++j) q_out[(size_t)row * NDOF + j] = qv[j];
 }
@@ -456,7 +515,7 @@ __global__ __launch_bounds__(64) void k_self_collision(const Chain* __restrict__
 // sibling of its pose has been valid at an iteration it has already completed (pose_first[j], an atomicMin over the repeats' first valid
 // iterations, 0xffffffff = none yet): whatever it found later could not be selected - the reference drops such rows from the batch
 // (q[mask] compaction, ikflow_solver.py:231-233).  A hint only: a late or missed update costs iterations, never a result.
-template <int NDOF>
+template <int NDOF, typename T>
 __global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict__ ch, const float* __restrict__ poses,
                                                         const int* __restrict__ pose_idx, int n_active, int repeat, int n_steps,
                                                         const float* q_in, float* q, uint8_t* __restrict__ row_valid_iter,
@@ -471,7 +530,7 @@ __global__ __launch_bounds__(256) void k_exact_lm_iters(const Chain* __restrict_
   const bool siblings = repeat > 1 && pose_first != nullptr;
   for (int it = 0; it < n_steps; ++it) {
     if (siblings && it > 0 && __hip_atomic_load(pose_first + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= (unsigned)it) break;
-    lm_step_row<NDOF>(ch, tgt, qv);
+    lm_step_row<NDOF, T>(ch, tgt, qv);
     float pe, re;
     pose_error_f32<NDOF>(ch, qv, tgt, &pe, &re);
     if (pe < pos_thr && re < rot_thr) {  // ikflow_solver.py:211
@@ -651,10 +710,13 @@ hipError_t launch_pose_error(const Chain* ch, int ndof, const float* q, const fl
   return hipGetLastError();
 }
 hipError_t launch_lm_step(const Chain* ch, int ndof, const float* tgt, const float* q, long long n, float* q_out,
-                          hipStream_t s) {
+                          int lm_precision, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_lm_step<ND>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, tgt, q, n,
-                                             q_out));
+  if (lm_precision == 0) {
+    IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_lm_step<ND, float>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, tgt, q, n, q_out));
+  } else {
+    IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_lm_step<ND, double>), dim3(blocks_for(n, 256)), dim3(256), 0, s, ch, tgt, q, n, q_out));
+  }
   return hipGetLastError();
 }
 hipError_t launch_jacobian(const Chain* ch, int ndof, const float* q, long long n, float* jac, hipStream_t s) {
@@ -698,16 +760,21 @@ hipError_t launch_self_collision(const Chain* ch, const CollisionModel* cm, int 
 }
 hipError_t launch_exact_lm_iters(const Chain* ch, int ndof, const float* poses, const int* pose_idx, int n_active, int repeat,
                                  int n_steps, const float* q_in, float* q, uint8_t* row_valid_iter, unsigned* pose_first, float pos_thr,
-                                 float rot_thr, hipStream_t s) {
+                                 float rot_thr, int lm_precision, hipStream_t s) {
   const long long rows = (long long)n_active * repeat;
   if (rows <= 0) return hipSuccess;
   if (n_steps > 255) return hipErrorInvalidValue;  // (the first-valid iteration is recorded in a byte)
   if (repeat > 1 && pose_first != nullptr) {  // "no repeat of this pose valid yet"
     if (hipError_t e = hipMemsetAsync(pose_first, 0xff, sizeof(unsigned) * (size_t)n_active, s); e != hipSuccess) return e;
   }
-  IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iters<ND>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch,
-                                             poses, pose_idx, n_active, repeat, n_steps, q_in, q, row_valid_iter,
-                                             repeat > 1 ? pose_first : nullptr, pos_thr, rot_thr));
+  unsigned* const pf = repeat > 1 ? pose_first : nullptr;
+  if (lm_precision == 0) {
+    IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iters<ND, float>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch, poses, pose_idx,
+                                               n_active, repeat, n_steps, q_in, q, row_valid_iter, pf, pos_thr, rot_thr));
+  } else {
+    IKF_NDOF_DISPATCH(ndof, hipLaunchKernelGGL((k_exact_lm_iters<ND, double>), dim3(blocks_for(rows, 256)), dim3(256), 0, s, ch, poses, pose_idx,
+                                               n_active, repeat, n_steps, q_in, q, row_valid_iter, pf, pos_thr, rot_thr));
+  }
   return hipGetLastError();
 }
 hipError_t launch_exact_select_first(int ndof, const int* pose_idx, int n_active, int repeat, const float* q,

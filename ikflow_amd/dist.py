@@ -44,11 +44,6 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     pad = torch.zeros((rows_max,) + tuple(cols), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((world * rows_max,) + tuple(cols), dtype=local.dtype, device=local.device)
-    if local.is_cuda and dist.get_backend(group) == "gloo":
-        # gloo stages device tensors through the host on its own streams; on this ROCm build that staging copy was seen to start before
-        # the work queued on the current stream had finished (stale rows in 1 of 8 runs of the two-ranks-on-one-GPU test) - with gloo
-        # (tests only: RCCL orders its kernels behind the current stream itself) the producer stream is drained first
-        torch.cuda.current_stream(local.device).synchronize()
     dist.all_gather_into_tensor(out, pad, group=group)
     if n_total == world * rows_max:
         return out
@@ -67,8 +62,6 @@ def gather_blocks(local: torch.Tensor, group=None, counts: Optional[Sequence[int
     if counts is None:
         mine = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
         every = torch.empty(world, dtype=torch.int64, device=local.device)
-        if local.is_cuda and dist.get_backend(group) == "gloo":
-            torch.cuda.current_stream(local.device).synchronize()
         dist.all_gather_into_tensor(every, mine, group=group)
         counts = [int(c) for c in every.tolist()]
     counts = [int(c) for c in counts]
@@ -83,8 +76,6 @@ def gather_blocks(local: torch.Tensor, group=None, counts: Optional[Sequence[int
         pad = torch.zeros((rows_max,) + cols, dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
     out = torch.empty((world * rows_max,) + cols, dtype=local.dtype, device=local.device)
-    if local.is_cuda and dist.get_backend(group) == "gloo":
-        torch.cuda.current_stream(local.device).synchronize()   # (see gather_rows)
     dist.all_gather_into_tensor(out, pad, group=group)
     if all(c == rows_max for c in counts):
         return out
@@ -124,7 +115,12 @@ def sharded_generate_ik_solutions_from_shard(solver, poses_shard: torch.Tensor, 
 def sharded_generate_exact_ik_solutions_from_shard(solver, poses_shard: torch.Tensor, *, counts: Optional[Sequence[int]] = None,
                                                    group=None, **kw):
     """generate_exact_ik_solutions on this rank's own pose block; solutions and valid flags of every rank in one collective."""
-    sol, valid = solver.generate_exact_ik_solutions(poses_shard, **kw)
+    if poses_shard.shape[0] == 0:   # (a rank without rows still takes part in the collective)
+        ndof = getattr(solver, "ndof", None) or getattr(getattr(solver, "robot", None), "ndof", None)
+        sol = torch.empty((0, int(ndof)), dtype=torch.float32, device=poses_shard.device)
+        valid = torch.empty((0,), dtype=torch.bool, device=poses_shard.device)
+    else:
+        sol, valid = solver.generate_exact_ik_solutions(poses_shard, **kw)
     full = gather_blocks(torch.cat([sol, valid.to(sol.dtype)[:, None]], dim=1), group, counts)
     return full[:, :-1].contiguous(), full[:, -1] > 0.5
 
@@ -133,13 +129,12 @@ class ShardedStepper:
     """Repeated steps over a fixed shard: one step = `compute()` on this rank's row block, then the path's one collective -
     all_gather_into_tensor of the [rows x cols] result into a preallocated, double-buffered [world * rows x cols] tensor.  On the GPU the
     gather runs on its own stream behind an event, so the gather of step i overlaps the flow of step i + 1; `fence()` drains both streams
-    and barriers.  On CPU tensors (gloo) the same calls run inline.  `sync_before_gather`: gloo with device tensors only (tests) - gloo's
-    host staging does not reliably wait for the stream it is issued on."""
+    and barriers.  On CPU tensors (gloo) the same calls run inline."""
 
     def __init__(self, compute: Callable[[], torch.Tensor], world: int, rank: int, rows: int, cols: int, device, use_dist: bool,
-                 n_buf: int = 2, sync_before_gather: bool = False, group=None):
+                 n_buf: int = 2, group=None):
         self.compute, self.world, self.rank, self.rows, self.device, self.use_dist = compute, world, rank, rows, device, use_dist
-        self.group, self.sync_before_gather = group, sync_before_gather
+        self.group = group
         self.cuda = torch.device(device).type == "cuda"
         self.n_buf = n_buf
         self.i = 0
@@ -156,8 +151,6 @@ class ShardedStepper:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
                 self.comm_stream.wait_event(ev)
-                if self.sync_before_gather:
-                    ev.synchronize()
                 with torch.cuda.stream(self.comm_stream):
                     dist.all_gather_into_tensor(self.gathered[k], sol, group=self.group)
                 sol.record_stream(self.comm_stream)
@@ -175,7 +168,11 @@ class ShardedStepper:
             torch.cuda.synchronize(self.device)
 
     def last_gathered(self) -> Optional[torch.Tensor]:
-        return self.gathered[(self.i - 1) % self.n_buf] if self.use_dist else None
+        """The gathered result of the most recent step - None before the first one (or without a process group).  With a side stream the
+        gather may still be in flight: call fence() first."""
+        if not self.use_dist or self.i == 0:
+            return None
+        return self.gathered[(self.i - 1) % self.n_buf]
 
 
 def sharded_rows(

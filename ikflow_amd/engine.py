@@ -180,6 +180,17 @@ class Engine:
     def precision(self) -> str:
         return {v: k for k, v in self.PRECISIONS.items()}[self.lib.ikf_get_precision(self._h)]
 
+    LM_PRECISIONS = {"f32": 0, "f64": 1}
+
+    def set_lm_precision(self, mode: str) -> None:
+        """Arithmetic of the LM step (include/ikflow_amd.h ikf_set_lm_precision): "f64" (default) = fp64 inside the step, Cholesky; "f32" =
+        the reference's own arithmetic (fp32 throughout, LU with partial pivoting as torch.linalg.solve, ikflow_solver.py:205,208)."""
+        self._ck(self.lib.ikf_set_lm_precision(self._h, self.LM_PRECISIONS[mode]))
+
+    @property
+    def lm_precision(self) -> str:
+        return {v: k for k, v in self.LM_PRECISIONS.items()}[self.lib.ikf_get_lm_precision(self._h)]
+
     def set_split_guard(self, on: bool) -> None:
         """f16x3 range guard (include/ikflow_amd.h ikf_set_split_guard): on (default) = one 4-byte flag read per call and an
         automatic f32 re-run when a hidden activation left the f16 range; off = no synchronisation, no re-run."""

@@ -107,7 +107,9 @@ int ikf_abi_version(void);
 ikf_status ikf_load_weights(ikf_model* m, const ikf_tensor* tensors, int n_tensors);
 int ikf_weights_loaded(const ikf_model* m);
 
-/* Pre-size the flow scratch for batches of up to max_rows flow rows. */
+/* Pre-size the flow scratch for batches of up to max_rows flow rows, and build every weight image a call of that size can reach on this
+ * handle (the small-batch per-layer kernels' image included - the form a cluster-form handle falls back to while another process holds
+ * CUs): after ikf_load_weights + ikf_reserve no ikf_generate_approx call of <= max_rows rows allocates or synchronises the device. */
 ikf_status ikf_reserve(ikf_model* m, int64_t max_rows);
 /* Pre-size the exact-IK state for max_poses target poses x max_repeat repeats, so that ikf_generate_exact allocates nothing.
  * Without it a call reserves its own worst case (n * max(repeat_counts) rows) up front while that is at most
@@ -208,6 +210,14 @@ ikf_status ikf_refine_exact(ikf_model* m, const float* d_target_poses, int64_t n
  *       kernel that produces a split operand flags a hidden activation that is non-finite or beyond that range. */
 ikf_status ikf_set_precision(ikf_model* m, int mode);
 int ikf_get_precision(const ikf_model* m);
+/* -- arithmetic of the Levenberg-Marquardt step (ikf_lm_step and every exact-IK entry point) ----------------- */
+/*   1 = (default) chain walk, Jacobian, J^T J + 1e-4 I and a Cholesky solve in fp64 inside the kernel, q rounded to fp32;
+ *   0 = the reference's own arithmetic: every quantity fp32 (ikflow/config.py:8 DEFAULT_TORCH_DTYPE; the step is jrl's
+ *       inverse_kinematics_step_levenburg_marquardt on fp32 tensors, ikflow_solver.py:205,208) and an LU solve with partial
+ *       pivoting - what torch.linalg.solve runs (LAPACK sgesv).  Agrees with the reference's CPU result to cond(J^T J + 1e-4 I) x
+ *       2^-24 per step, the reference's own rounding noise. */
+ikf_status ikf_set_lm_precision(ikf_model* m, int mode);
+int ikf_get_lm_precision(const ikf_model* m);
 /* Range guard of mode 1.  guard = 1 (default): every call ends by reading the flag (4-byte copy + stream synchronisation) and,
  * if set, runs again on the exact-f32 path (counted).  guard = 0: no synchronisation, no re-run; the flag accumulates on the
  * device until ikf_split_overflow_pending() reads and clears it (synchronises `stream`). */

@@ -41,8 +41,9 @@ ikf_status ikf_plan_describe(ikf_model* m, int64_t rows, char* buf, int buf_len)
  * load agreed, and no launch has met a member elsewhere since); 0: hand-over through memory. */
 int ikf_cluster_local(ikf_model* m);
 /* Calls the cluster form still sits out on this handle: a wait inside one of its launches ran out (another process's kernel held CUs; the
- * rows were recomputed by the repair launch and ikf_cluster_repairs counted it), so the form pauses for 16 calls, twice as many after every
- * further give-up (at most 65536), and is tried again afterwards; 64 clean cluster calls in a row forget the history.  0: in use. */
+ * rows were recomputed by the repair launch and ikf_cluster_repairs counted it), so the form pauses for 16 plans, twice as many after every
+ * further give-up (at most 65536), and is tried again afterwards; 64 clean cluster plans in a row forget the history.  A plan = one cut of a
+ * batch into chunks: ikf_generate_approx makes one per call, an exact-IK call one per retry round.  0: in use. */
 int64_t ikf_cluster_backoff(ikf_model* m);
 /* What first use costs: host wall time (ms) of the last ikf_load_weights on this handle - the packing, the upload and the device-side
  * images of the resident-row forms included - and of building the small-batch per-layer kernels' weight image, which only the first

@@ -238,9 +238,12 @@ def calculate_joint_limits_exceeded(configs: torch.Tensor, joint_limits) -> torc
 # loop can be driven by the torch oracle flow (CPU parity) or by recorded seeds.
 # ---------------------------------------------------------------------------------------------------
 def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_opt_steps_max=3, lm_dtype=torch.float32,
-                margins=None):
+                margins=None, q_ulps=0):
     """One call of _generate_exact_ik_solutions given the clamped flow seeds q [n*R x ndof] (tile-major).
     lm_dtype=float64 evaluates each LM step in double and rounds q back to float32 (what the HIP kernel does).
+    ``q_ulps`` (tests): every q that leaves an LM step is moved by that many fp32 ulps - the twin run that measures, pose by pose, what a
+    last-bit difference in an intermediate iterate does to the result (the step map amplifies along the arm's self-motion by up to
+    |e| |d2x/dq2| / lambda).
     ``margins`` (optional, [n, 2] float tensor, updated in place): per pose the smallest |pos_err - pos_thr| and
     |rot_err - rot_thr| seen over every (iteration, repeat) evaluated for it - lets a test exclude poses whose validity
     flag hangs on rounding."""
@@ -255,6 +258,8 @@ def exact_round(robot, seeds_q, target_poses, repeat_count, pos_thr, rot_thr, n_
     for _ in range(n_opt_steps_max):
         assert len(q) == n_invalid * repeat_count
         q = lm_step(robot, poses_tiled.to(lm_dtype), q.to(lm_dtype)).to(torch.float32)
+        for _u in range(abs(int(q_ulps))):
+            q = torch.nextafter(q, torch.full_like(q, float("inf") if q_ulps > 0 else -float("inf")))
         q = clamp_to_joint_limits(robot, q)
         pos_err, rot_err = calculate_pose_error(robot, q, poses_tiled)
         valids_tiled = torch.logical_and(pos_err < pos_thr, rot_err < rot_thr)
@@ -308,7 +313,7 @@ def generate_exact_ik_solutions(robot, flow_fn, target_poses, latents: List[torc
 
 
 def generate_exact_ik_solutions_seeded(robot, seed_fn, target_poses, repeat_counts=(1, 3, 10), pos_thr=1e-3, rot_thr=0.1,
-                                       lm_dtype=torch.float32, return_margins=False):
+                                       lm_dtype=torch.float32, return_margins=False, q_ulps=0):
     """The same retry schedule (ikflow_solver.py:345-411) with the flow taken out: ``seed_fn(round, pose_indices) ->
     [len(pose_indices) * R_round x ndof]`` supplies the (clamped) seeds of the still-invalid poses, tile-major
     (row = r * n_active + j, as ``conditional.repeat((R, 1))`` lays them out, :185).  Drives exactly the part of the path
@@ -327,7 +332,7 @@ def generate_exact_ik_solutions_seeded(robot, seed_fn, target_poses, repeat_coun
         seeds = seed_fn(r, idx)
         assert seeds.shape == (idx.numel() * R, robot.ndof), (seeds.shape, idx.numel(), R)
         sub = torch.full((idx.numel(), 2), float("inf"), dtype=torch.float64)
-        new_sol, new_valid = exact_round(robot, seeds, missing, R, pos_thr, rot_thr, lm_dtype=lm_dtype, margins=sub)
+        new_sol, new_valid = exact_round(robot, seeds, missing, R, pos_thr, rot_thr, lm_dtype=lm_dtype, margins=sub, q_ulps=q_ulps)
         margins[idx] = torch.minimum(margins[idx], sub)
         solutions[idx, :] = new_sol
         valids[idx] = new_valid

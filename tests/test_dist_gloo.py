@@ -256,6 +256,9 @@ def _worker_real_solver(rank, world, port, n, q, backend="gloo"):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
+        import gloo_staging
+
+        gloo_staging.install()   # gloo never sees a device tensor (tests/gloo_staging.py)
         dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         assert dist.get_backend() == backend and dist.get_world_size() == world

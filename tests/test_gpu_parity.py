@@ -885,9 +885,17 @@ def test_exact_ik_seeded_is_row_exact_against_the_oracle(which, pos_thr, rot_thr
     both = clear & valid & ref_valid
     d = (sol[both] - ref_sol[both]).abs().max(1).values
     print(f"   |hip - oracle| on {int(both.sum())} both-valid poses: max {d.max().item():.2e}")
-    # (5e-6 on every pose is what these seeds measure, run after run; the second clause only keeps a straggler - an fp32 rounding of q that went
-    # to the other neighbour on one side, times the next LM step's sensitivity: see test_exact_ik_seeded_random_schedules - from failing a run)
-    assert d.max().item() <= 5e-6 or (int((d > 5e-6).sum()) <= 2 and d.max().item() <= 1e-4), (d.max().item(), int((d > 5e-6).sum()))
+    # 5e-6 on every pose, plus - pose by pose - what the pose's OWN conditioning allows: the oracle is run a second time with every iterate that
+    # leaves an LM step moved by one fp32 ulp; |twin - oracle| on a pose is what a last-bit difference in an intermediate q does to ITS result
+    # (the step map amplifies along the arm's self-motion by up to |e| |d2x/dq2| / lambda).  The two sides differ by such last-bit amounts (the
+    # kernel's chain constants are fp32, the oracle's fp64), so a pose may sit as far from the oracle as SENS_FACTOR of its own twins do.
+    twin_sol, twin_valid = ko.generate_exact_ik_solutions_seeded(robot, seed_cpu, poses, rc, pos_thr, rot_thr, lm_dtype=torch.float64, q_ulps=1)
+    sens = (twin_sol - ref_sol).abs().max(1).values[both]
+    sens[~twin_valid[both]] = float("inf")   # (a pose whose flag a last-bit nudge flips is a band pose in all but name)
+    SENS_FACTOR = 8.0
+    allowed = 5e-6 + SENS_FACTOR * sens
+    print(f"   poses beyond 5e-6: {int((d > 5e-6).sum())}; max d / allowed {float((d / allowed).max()):.2f}; twin sensitivity max {float(sens[torch.isfinite(sens)].max()):.2e}")
+    assert bool((d <= allowed).all()), (float(d.max()), float((d / allowed).max()), int((d > 5e-6).sum()))
     assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
     assert int(stats[0, 0]) == n and int(valid.sum()) == int(stats[:, 3].sum())
     # per-round bookkeeping agrees with the oracle's up to the band poses
@@ -910,6 +918,110 @@ def test_exact_ik_seeded_is_row_exact_against_the_oracle(which, pos_thr, rot_thr
           f"p99 {d32[1]:.2e} max {d32[2]:.2e}; |q_f64 - q_cpu32| median {o32[0]:.2e} p99 {o32[1]:.2e} max {o32[2]:.2e}")
     assert agree >= 0.95 and agree >= agree_twins - 0.005
     assert d32[0] <= 1.5 * o32[0] + 1e-6 and d32[1] <= 1.5 * o32[1] + 1e-5
+
+
+def test_exact_ik_in_the_reference_lm_arithmetic():
+    """BASELINE config 3 in the reference's OWN arithmetic (ikf_set_lm_precision 0): fp32 chain walk, Jacobian, J^T J + 1e-4 I
+    and an LU / partial-pivoting solve - what jrl's step does on fp32 tensors (ikflow/config.py:8, ikflow_solver.py:199-211, torch.linalg.solve
+    = LAPACK sgesv).  n = 4096, repeat_counts (1, 3, 10), identical seeds, compared pose by pose with the oracle's fp32 loop.
+
+    What can be asked of two fp32 evaluations of this step: J^T J of a 7-joint arm in a 6-D task has rank 6, so cond(J^T J + 1e-4 I) =
+    sigma_max^2 / 1e-4 + 1 >= 1e4 on EVERY pose (measured 3.5e4 +- 10 %, profiles/r06_lm_precision.json) - each side carries cond x 2^-24 of its
+    step as rounding noise (the fp32 reference itself sits 2.6e-5 median / 3.5e-4 max from the fp64 evaluation of ONE step).  So:
+      * every pose with cond < 1e3 must agree to 1e-5 (there are none on these arms: the count is printed and asserted on, not assumed);
+      * on the rest the HIP fp32 loop must be statistically the reference loop: as close to the oracle's fp32 loop as the oracle's fp64 loop is
+        (median and p99 within 1.5x), flags agreeing at least as often."""
+    from ikflow_amd.engine import kinematics_engine_for
+    from ikflow_amd.robots import get_robot
+
+    robot = get_robot("panda")
+    n, rc, pos_thr, rot_thr = 4096, (1, 3, 10), 1e-3, 0.01
+    q_true, poses = reachable_poses(robot, n, 61)
+    tables = _seed_tables(robot, q_true, rc, 62)
+
+    def seed_cpu(rnd, idx):
+        return tables[rnd][:, idx, :].reshape(-1, robot.ndof).contiguous()
+
+    ref32_sol, ref32_valid = ko.generate_exact_ik_solutions_seeded(robot, seed_cpu, poses, rc, pos_thr, rot_thr, lm_dtype=torch.float32)
+    ref64_sol, ref64_valid = ko.generate_exact_ik_solutions_seeded(robot, seed_cpu, poses, rc, pos_thr, rot_thr, lm_dtype=torch.float64)
+    eng = kinematics_engine_for(robot, DEV)
+    assert eng.lm_precision == "f64"
+    eng.set_lm_precision("f32")
+    assert eng.lm_precision == "f32"
+    dev_tables = [t.to(DEV) for t in tables]
+
+    def seed_dev(rnd, idx, repeat):
+        return dev_tables[rnd][:, idx, :].reshape(-1, robot.ndof).contiguous()
+
+    sol, valid, stats = eng.generate_exact(poses.to(DEV), rc, pos_thr, rot_thr, seed_fn=seed_dev, return_stats=True)
+    again, valid_again = eng.generate_exact(poses.to(DEV), rc, pos_thr, rot_thr, seed_fn=seed_dev)
+    assert torch.equal(sol, again) and torch.equal(valid, valid_again)   # deterministic
+    sol, valid = sol.cpu(), valid.cpu()
+    # every returned solution meets the thresholds (fp32 FK, as the reference checks it) and unsolved rows are zero
+    pe, re = ko.calculate_pose_error(robot, sol[valid], poses[valid])
+    assert float(pe.max()) < pos_thr + 5e-7 and float(re.max()) < rot_thr + 6e-7 / rot_thr
+    assert torch.equal(sol[~valid], torch.zeros_like(sol[~valid]))
+    both = valid & ref32_valid
+    d = (sol[both] - ref32_sol[both]).abs().max(1).values
+    J = ko.jacobian(robot, ref32_sol[both].double())
+    cond = torch.linalg.cond(J.transpose(1, 2) @ J + 1e-4 * torch.eye(robot.ndof, dtype=torch.float64))
+    well = cond < 1e3
+    print(f"fp32 LM mode: valid {int(valid.sum())}/{n} (oracle fp32 loop {int(ref32_valid.sum())}, fp64 loop {int(ref64_valid.sum())}); cond min {float(cond.min()):.3g} "
+          f"median {float(cond.median()):.3g} max {float(cond.max()):.3g}; poses with cond < 1e3: {int(well.sum())}")
+    if bool(well.any()):
+        assert float(d[well].max()) <= 1e-5
+    assert float(cond.min()) >= 1e3, "a rank-6 J^T J + 1e-4 I cannot be better conditioned than sigma_max^2 / 1e-4"
+
+    def dist(a, b, m):
+        d_ = (a[m] - b[m]).abs().max(1).values
+        return float(d_.median()), float(d_.quantile(0.99)), float(d_.max())
+
+    h32 = dist(sol, ref32_sol, both)
+    o64 = dist(ref64_sol, ref32_sol, ref64_valid & ref32_valid)
+    agree, agree_twins = float((valid == ref32_valid).float().mean()), float((ref64_valid == ref32_valid).float().mean())
+    for lo, hi in ((1e3, 1e4), (1e4, 2e4), (2e4, 3e4), (3e4, 4e4), (4e4, 1e5), (1e5, float("inf"))):
+        mk = (cond >= lo) & (cond < hi)
+        if bool(mk.any()):
+            print(f"   cond [{lo:.0e}, {hi:.0e}): {int(mk.sum())} poses, |q_hip32 - q_cpu32| median {float(d[mk].median()):.2e} p99 {float(d[mk].quantile(0.99)):.2e} max {float(d[mk].max()):.2e}")
+    print(f"   |q_hip32 - q_cpu32| median {h32[0]:.2e} p99 {h32[1]:.2e} max {h32[2]:.2e}; |q_cpu64 - q_cpu32| median {o64[0]:.2e} p99 {o64[1]:.2e} max {o64[2]:.2e}; "
+          f"flags agree {agree:.4f} (fp64 loop vs fp32 loop {agree_twins:.4f})")
+    assert h32[0] <= 1.5 * o64[0] + 1e-6 and h32[1] <= 1.5 * o64[1] + 1e-5
+    assert agree >= agree_twins - 0.005
+    eng.set_lm_precision("f64")
+
+
+def test_lm_step_in_the_reference_arithmetic_carries_the_reference_noise():
+    """One LM step on 4096 perturbed seeds, three evaluations: the oracle in fp32 (the reference's arithmetic), the kernel in fp32 mode, and fp64
+    truth.  In units of cond x 2^-24 x |dq| - the rounding noise of ANY fp32 evaluation of (J^T J + 1e-4 I)^-1 J^T e - the kernel's fp32 step is
+    as close to truth as the oracle's, and the two agree with one another to that noise; the default fp64-inside step is ~300x closer."""
+    from ikflow_amd.engine import kinematics_engine_for
+    from ikflow_amd.robots import get_robot
+
+    robot = get_robot("panda")
+    n = 4096
+    q_true, poses = reachable_poses(robot, n, 0)
+    seeds = ko.clamp_to_joint_limits(robot, q_true + 0.05 * torch.randn(q_true.shape, generator=torch.Generator().manual_seed(3)))
+    J = ko.jacobian(robot, seeds.double())
+    cond = torch.linalg.cond(J.transpose(1, 2) @ J + 1e-4 * torch.eye(robot.ndof, dtype=torch.float64))
+    ref32 = ko.lm_step(robot, poses, seeds)
+    ref64 = ko.lm_step(robot, poses.double(), seeds.double())
+    unit = cond * 2.0 ** -24 * (ref64 - seeds.double()).abs().max(1).values.clamp_min(1e-3)
+    eng = kinematics_engine_for(robot, DEV)
+    out = {}
+    for mode in ("f32", "f64"):
+        eng.set_lm_precision(mode)
+        got = eng.lm_step(poses.to(DEV), seeds.to(DEV)).cpu().double()
+        out[mode] = ((got - ref64).abs().max(1).values / unit, (got - ref32.double()).abs().max(1).values / unit)
+    eng.set_lm_precision("f64")
+    o32 = (ref32.double() - ref64).abs().max(1).values / unit
+    q = lambda t: (float(t.median()), float(t.quantile(0.99)), float(t.max()))
+    print(f"LM step, errors in units of cond eps |dq| (median, p99, max): oracle fp32 vs truth {q(o32)}; hip fp32 vs truth {q(out['f32'][0])}, vs oracle fp32 "
+          f"{q(out['f32'][1])}; hip fp64 vs truth {q(out['f64'][0])}")
+    assert float(cond.min()) >= 1e3
+    assert q(out["f32"][0])[0] <= 1.5 * q(o32)[0] and q(out["f32"][0])[1] <= 1.5 * q(o32)[1]     # as close to truth as the reference's arithmetic
+    assert q(out["f32"][1])[1] <= 2.5 * q(o32)[1]                                               # and to the reference itself, to that noise
+    assert float(out["f32"][0].max()) <= 16.0 and float(o32.max()) <= 16.0                       # nobody exceeds the noise model by an order
+    assert q(out["f64"][0])[2] <= 0.05                                                          # fp64 inside: two orders below it
 
 
 def _random_exact_configs(count, seed):
@@ -1646,16 +1758,24 @@ def test_cluster_form_is_tried_again_after_a_pause_that_doubles():
         torch.cuda.synchronize()
         assert torch.equal(back, good), "the cluster form again, bit for bit"
         assert eng.cluster_repairs == round_
-    # ... and at its usual speed (0.50 ms on an idle MI355X; the per-layer kernels it replaced during the pause take 0.71)
-    for _ in range(20):
-        s.generate_ik_solutions(P, latent=L)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(50):
-        s.generate_ik_solutions(P, latent=L)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 50 * 1e3
-    assert ms <= 0.62, f"{ms:.3f} ms per 512-row call after the pause"
+    # ... and at its usual speed: faster than the per-layer kernels that replaced it during the pause, timed in the same run on the same GPU
+    # (0.48 against 0.71 ms on an idle MI355X; no absolute bound - a shared or down-clocked GPU is exactly where the pause matters)
+    def ms_per_call():
+        for _ in range(20):
+            s.generate_ik_solutions(P, latent=L)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            s.generate_ik_solutions(P, latent=L)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 50 * 1e3
+
+    ms = ms_per_call()
+    eng.set_gemm_variant(185)
+    assert "cluster" not in eng.plan(n)
+    ms_per_layer = ms_per_call()
+    eng.set_gemm_variant(186)
+    assert ms < ms_per_layer, f"{ms:.3f} ms per 512-row call after the pause against {ms_per_layer:.3f} on the per-layer kernels"
     s.load_state_dict_tensors(sd)
     assert s.engine(DEV).cluster_backoff == 0
 
@@ -1724,8 +1844,9 @@ def test_cluster_form_tagged_buffers_after_a_give_up_with_calls_already_queued()
 @pytest.mark.gpu
 def test_small_batch_weight_image_is_built_on_first_use_only():
     """The fragment-major image of the small-batch per-layer kernels (+ 201 MB for Panda, 48 pack launches) is no longer part of
-    ikf_load_weights: a handle whose small batches run the cluster form never builds it; the first <= 512-row chunk that does take the
-    per-layer path builds it (same results as before), and ikf_reserve does so ahead of time on a handle that can reach that path."""
+    ikf_load_weights: a handle whose small batches run the cluster form does not build it by itself; the first <= 512-row chunk that does take
+    the per-layer path builds it (same results as before), and ikf_reserve ALWAYS does so ahead of time (r06) - a cluster-form handle falls back
+    to these kernels while another process holds CUs, the worst moment for an allocation and a device-wide synchronisation inside a call."""
     robot, hp, lay, sd = panda_model()
     s = _solver(robot, hp, sd)
     eng = s.engine(DEV)
@@ -1736,8 +1857,6 @@ def test_small_batch_weight_image_is_built_on_first_use_only():
     assert eng.load_time_ms > 0.0 and eng.frag_image_time_ms == 0.0
     by_plan = s.generate_ik_solutions(P, latent=L).clone()
     assert eng.plan(n).startswith("cluster") and eng.frag_image_time_ms == 0.0
-    eng.reserve(4096)
-    assert eng.frag_image_time_ms == 0.0, "no call on this handle reaches the per-layer kernels"
     eng.set_gemm_variant(180)
     eng.set_gemm_variant(185)
     assert eng.plan(n) == f"perlayer:{n}"
@@ -1747,14 +1866,16 @@ def test_small_batch_weight_image_is_built_on_first_use_only():
     assert (per_layer - by_plan).abs().max().item() <= FLOW_TOL
     ref = fo.generate_ik_solutions_torch(sd, lay, robot, poses, lat)
     assert (per_layer.cpu() - ref).abs().max().item() <= FLOW_TOL
-    # a handle that starts on the per-layer path: ikf_reserve builds the image before the first call
+    # ikf_reserve builds the image before the first call - on a default handle (cluster form allowed) too
     s2 = _solver(robot, hp, sd)
     e2 = s2.engine(DEV)
+    assert e2.plan(n).startswith("cluster") and e2.frag_image_time_ms == 0.0
+    e2.reserve(512)
+    built = e2.frag_image_time_ms
+    assert built > 0.0
     e2.set_gemm_variant(180)
     e2.set_gemm_variant(185)
-    e2.reserve(512)
-    assert e2.frag_image_time_ms > 0.0
-    assert torch.equal(s2.generate_ik_solutions(P, latent=L), per_layer)
+    assert torch.equal(s2.generate_ik_solutions(P, latent=L), per_layer) and e2.frag_image_time_ms == built
 
 
 @pytest.mark.parametrize("n", [129, 200, 256, 257, 300, 500, 512, 700, 1000, 1024])
@@ -1812,6 +1933,35 @@ def test_cluster_form_xcd_local_placement_check_falls_back_to_the_spread_form():
     assert torch.equal(again, good) and eng.cluster_repairs == 1
     eng.set_gemm_variant(191)                       # (no XCD-local launch any more: the hook stays unused, nothing gives up)
     assert torch.equal(s.generate_ik_solutions(P, latent=L), good) and eng.cluster_repairs == 1
+
+
+def test_cluster_form_tagged_xcd_local_placement_check_in_every_launch():
+    """The DEFAULT hand-over (tagged payload) in its XCD-local form assumes nothing about placement either (r06): it has no epoch words, so every
+    member writes (launch number, XCC_ID) into a word of its own at the start of every launch, and once per launch - in front of the first
+    payload read - a member compares its peers' ids with its own.  Variant 191 makes workgroup 0 claim another XCD: its peers give up with the
+    placement code, the repair launch recomputes the rows, the handle goes on with the SPREAD form (not without the cluster form, and without
+    a pause), same bits as before."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    n = 512
+    _, poses = reachable_poses(robot, n, 163)
+    lat = latents(n, lay.dim, 164)
+    P, L = poses.to(DEV), lat.to(DEV)
+    eng.set_gemm_variant(182)
+    ro = s.generate_ik_solutions(P, latent=L).clone()
+    eng.set_gemm_variant(181)
+    good = [s.generate_ik_solutions(P, latent=L).clone() for _ in range(3)]   # (consecutive launches: another launch number each)
+    assert all(torch.equal(g, good[0]) for g in good) and eng.cluster_repairs == 0 and eng.cluster_local and eng.plan(n) == "cluster8:512"
+    eng.set_gemm_variant(191)
+    out = torch.full_like(ro, float("nan"))
+    out.copy_(s.generate_ik_solutions(P, latent=L))
+    torch.cuda.synchronize()
+    assert torch.equal(out, ro), "the repair launch's rows"
+    assert eng.cluster_repairs == 1 and not eng.cluster_local and eng.cluster_backoff == 0 and eng.plan(n) == "cluster8:512"
+    again = s.generate_ik_solutions(P, latent=L)
+    torch.cuda.synchronize()
+    assert torch.equal(again, good[0]) and eng.cluster_repairs == 1   # spread placement: the same tagged values through another memory path
 
 
 def test_plan_of_a_call_by_batch_size():

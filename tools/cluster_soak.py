@@ -1,6 +1,6 @@
 """Randomised soak of the cluster form's default hand-over (parity-tagged payload, no drain / epoch words / memset): thousands of calls of random
 sizes 129 .. 3300 queued with hardly any synchronisation, every result compared with the same rows through the row-owner launch (no
-inter-workgroup hand-over at all), plus a give-up injected now and then (ikf_set_gemm_variant 188).  usage: python tools/cluster_soak.py [calls=3000]"""
+inter-workgroup hand-over at all), plus a give-up injected now and then (ikf_set_gemm_variant 188).  usage: python tools/cluster_soak.py [calls=3000] [give_up_every=500]"""
 import json
 import os
 import sys
@@ -17,6 +17,7 @@ from helpers import latents, panda_model, reachable_poses  # noqa: E402
 from ikflow_amd.ikflow_solver import IKFlowSolver  # noqa: E402
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+every = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 dev = torch.device("cuda:0")
 robot, hp, lay, sd = panda_model(gain=2.0)
 s = IKFlowSolver(hp, robot)
@@ -35,7 +36,7 @@ pending = []
 for c in range(calls):
     n = int(rng.integers(129, N + 1))
     lo = int(rng.integers(0, N - n + 1))
-    if c % 500 == 250:
+    if c % every == every // 2:
         eng.set_gemm_variant(188)      # the next cluster launch runs a workgroup short: waits run out, repair launch, pause, buffers re-created
         injected += 1
     out = s.generate_ik_solutions(P[lo:lo + n], latent=L[lo:lo + n])
