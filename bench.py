@@ -443,6 +443,14 @@ def live_profile(kernel_substr="k_flow_gemm<"):
                     calls += int(r["Calls"])
                     total += float(r["TotalDurationNs"])
             out["avg_us"] = total / calls / 1e3 if calls else None
+            # the same trace, launch by launch: median and steady-state mean (launches behind an idle gap of the queue - the clock ramp - left out)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from kernel_trace_steady import kernel_trace_stats
+
+                out["trace"] = kernel_trace_stats(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)[0], kernel_substr)
+            except Exception:
+                out["trace"] = None
         finally:
             shutil.rmtree(d, ignore_errors=True)
         out["note"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes; traffic = 2 x FETCH_SIZE + "
@@ -450,6 +458,21 @@ def live_profile(kernel_substr="k_flow_gemm<"):
     except Exception as e:  # never let the profiler leg take the bench line down
         out["note"] = f"rocprofv3 leg failed ({type(e).__name__}); committed profile figures reported instead"
     return out
+
+
+def rocprof_kernel_steady(kernel_substr):
+    """The committed launch-by-launch summary of the same command's kernel trace (profiles/rNN_bench_kernel_steady.json, written by
+    tools/kernel_trace_steady.py inside tools/profile_round.sh); (None, None) if absent or for another kernel."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_kernel_steady.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return (d, os.path.basename(files[-1])) if d and d.get("kernel") == kernel_substr else (None, None)
+    except Exception:
+        return None, None
 
 
 def rocprof_kernel_avg_us(kernel_substr="k_flow_gemm<"):
@@ -787,7 +810,13 @@ def main():
     live_traffic, live_note = live["traffic"], live["note"]
     if live["avg_us"] is not None:
         prof_us, prof_src = live["avg_us"], "rocprofv3 --kernel-trace --stats in this run"
-    extra = {"flow_tflops_per_gpu": round(flow_tflops, 2), "frac_of_fp32_mfma_peak_end_to_end": round(flow_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
+    # launch by launch: the steady-state mean (the clock ramp behind the trace's idle gaps left out) is what `roofline.frac` is computed from
+    trace, trace_src = (live.get("trace"), "rocprofv3 --kernel-trace in this run") if live.get("trace") else (rocprof_kernel_steady(ksub) if headline_cfg else (None, None))
+    steady_us = trace.get("steady_mean_us") if trace else None
+    frac_event = achieved / FP32_MFMA_PEAK_TFLOPS
+    frac_steady = (flop_per_launch / (steady_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if steady_us else None
+    extra = {"cluster_repairs": int(eng.cluster_repairs),   # calls in which a cluster-form wait ran out (another process held CUs): repaired, counted
+             "flow_tflops_per_gpu": round(flow_tflops, 2), "frac_of_fp32_mfma_peak_end_to_end": round(flow_tflops / FP32_MFMA_PEAK_TFLOPS, 4),
              "gemm_ms": round(gemm_ms, 5), "gemm_launches_per_step": launches_per_step, "first_use": first_use}
     if args.precision == "f32" and not args.no_split_extra:
         # the same workload with the hidden contractions on the error-compensated 3x f16 MFMA split (opt-in precision mode;
@@ -861,8 +890,14 @@ def main():
                                + (f" (fixed global batch of {args.global_batch} poses per step split over the ranks)" if mode == "strong" else ""),
                    "global_batch": asked, "rows_per_rank": B, "padded_rows": world * B - asked, "scaling_mode": mode,
                    "parallelism": f"rows sharded x{world}, weights replicated, 1 all-gather/step"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": live_traffic if live_traffic is not None else traffic,
+        "roofline": {"bound": "mfma", "achieved": (frac_steady * FP32_MFMA_PEAK_TFLOPS) if frac_steady else achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     # `frac`: from the profiler's own clock - the steady-state mean launch duration of the rocprofv3 kernel trace (reproducible from
+                     # profiles/); `frac_event`: the hipEvent pairs around the launches inside real calls; `frac_rocprof`: the trace's raw average
+                     # (what --stats prints: includes the clock-ramp launches behind the trace's idle gaps)
+                     "frac": frac_steady if frac_steady else frac_event, "frac_source": (f"steady-state mean of {trace_src}" if frac_steady else "hipEvent pairs (no kernel trace available)"),
+                     "frac_event": frac_event, "achieved_event": achieved,
+                     "kernel_trace": trace, "kernel_trace_source": trace_src,
+                     "traffic": live_traffic if live_traffic is not None else traffic,
                      "traffic_unit": "HBM bytes per launch",
                      "traffic_source": live_note if live_traffic is not None else traffic_src,
                      "traffic_committed": traffic, "traffic_committed_source": traffic_src, "traffic_live_note": live_note,

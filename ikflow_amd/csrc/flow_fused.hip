@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT) void k_subnet_entry(EntryArgs e) {
 }
 
 // The next subnet's entry phase in the tail of a contraction (TailSync: tail_next_entry) and the one-launch subnet chain for <= 128 rows
-// (k_flow_chain16) - priced and rejected in round 3 (DESIGN_LOG.md section A) - live in flow_fused_probes.inc and exist only in the probes
+// (k_flow_chain16) - priced and rejected in round 3 (CHANGELOG.md; measurement log in git history) - live in flow_fused_probes.inc and exist only in the probes
 // library (-DIKF_PROBES).  The FUSE template parameter of the two contraction kernels below is never instantiated true in the product.
 [[maybe_unused]] constexpr unsigned kTailSpinLimit = 1u << 21;  // x (s_sleep 8 + one load) ~ a second: only reached when a sibling never runs
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
@@ -1751,7 +1751,7 @@ static hipError_t launch_entry_gemm16(const EntryArgs& e, const FusedGemmArgs& a
   return hipGetLastError();
 }
 
-// ---- the priced alternatives of rounds 2 - 3 ("measurement log") are compiled only into the probes library
+// ---- the priced alternatives of rounds 2 - 3 (CHANGELOG.md; measurement log in git history) are compiled only into the probes library
 // (-DIKF_PROBES, ikflow_amd/lib/libikflow_amd_probes.so): the one-launch subnet chain for <= 128 rows (k_flow_chain16), the next subnet's
 // entry phase in the tail of a contraction (TailSync), tile configurations 5 / 7 / 11.  The shipped library answers "not supported".
 #ifndef IKF_PROBES

@@ -63,6 +63,9 @@ def main():
                               "vs_oracle_f32_max": float(e32.max()), "vs_f64_truth_max": float(e64.max()),
                               "vs_f64_truth_in_units_of_cond_eps_step": {k: float(np.quantile(e64 / unit, v)) for k, v in (("p50", 0.5), ("p99", 0.99), ("max", 1.0))},
                               "vs_oracle_f32_in_units_of_cond_eps_step": {k: float(np.quantile(e32 / unit, v)) for k, v in (("p50", 0.5), ("p99", 0.99), ("max", 1.0))}}
+        top = np.argsort(-(e64 / unit))[:5]
+        res["hip_" + mode]["worst_rows_vs_truth"] = [{"row": int(i), "units": float(e64[i] / unit[i]), "abs": float(e64[i]), "cond": float(cond[i]), "step": float(step[i]),
+                                                      "q_hip": [float(v) for v in got[i]], "q_truth": [float(v) for v in ref64[i]], "q_oracle32": [float(v) for v in ref32[i]]} for i in top]
     eo = (ref32.double() - ref64).abs().max(dim=1).values.numpy()
     res["oracle_f32"] = {"vs_f64_truth_by_cond": strat(cond, eo), "vs_f64_truth_max": float(eo.max()),
                          "vs_f64_truth_in_units_of_cond_eps_step": {k: float(np.quantile(eo / unit, v)) for k, v in (("p50", 0.5), ("p99", 0.99), ("max", 1.0))}}

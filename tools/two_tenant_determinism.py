@@ -90,7 +90,7 @@ def main():
     differing = 0
     with open(a.out, "w") as f:
         for case in CASES:
-            if a.only and a.only not in case["name"]:
+            if a.only and a.only != case["name"]:
                 continue
             n_t = case["tenants"]
             q, barrier = ctx.Queue(), ctx.Barrier(n_t)
