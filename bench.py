@@ -10,8 +10,9 @@ seeded random (nn.Linear default init) of the released architecture `panda__full
 is a remote URL and there is no network.  With N > 1 every rank processes its own 4096-row shard (weak scaling) and the
 step ends with the one RCCL all-gather of the [4096 x 7] solutions.
 
-Rank 0 prints ONE JSON line: metric/value/unit per BASELINE.json, `roofline` for the dominant kernel (k_flow_gemm: the
-[B x 1024].[1024 x 1024]^T fp32-MFMA contraction), `cpu_baseline` (the torch-CPU oracle timed on this host's cores on
+Rank 0 prints ONE JSON line: metric/value/unit per BASELINE.json, `roofline` for the dominant kernel (k_flow_rowowner: the whole
+inverse pass of the batch in one launch, FP32-MFMA bound; `frac` from the steady-state mean launch duration of a rocprofv3 kernel
+trace of this command, `frac_event` from hipEvent pairs around the launches inside real calls), `cpu_baseline` (the torch-CPU oracle timed on this host's cores on
 a bounded sample; N=1 only), and - N=1 only, bounded to about a minute - `extra.cells`: the other cells of BASELINE.json's
 metric ("approx + exact, batch 512/4096", FetchArm B=8192), each with ms, rate, flow rows/s and its own fraction of the
 FP32-MFMA roofline.

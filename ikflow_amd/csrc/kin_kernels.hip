@@ -192,8 +192,13 @@ __device__ __forceinline__ void solve_cholesky(double A[NDOF][NDOF], double g[ND
 // Solve A x = g in place (x -> g), A full: LU with partial pivoting, then the two triangular solves - what torch.linalg.solve does on the
 // reference's fp32 tensors (LAPACK sgesv = sgetrf + sgetrs; ikflow_solver.py:205,208 -> jrl).  Everything stays in registers: the pivot
 // row is found by an unrolled compare and the swap is an unrolled select, so no index is a run-time value.
+// Every operation of the elimination is rounded on its own (no fused multiply-adds), as in the reference routine: with the compiler's
+// contraction the poses next to a singularity (TWO eigenvalues of J^T J + 1e-4 I near 1e-4) came out up to 9.5 x cond x 2^-24 x |dq| from the fp64
+// step - 6 x outside what the oracle's sgesv, and this code without contraction, leave (r06, tools/lm_precision_report.py; the median and p99 were
+// the same either way).  Cost: nothing measurable (a 7 x 7 solve per row).
 template <int NDOF>
 __device__ __forceinline__ void solve_lu_pivot(float A[NDOF][NDOF], float g[NDOF]) {
+#pragma clang fp contract(off)
 #pragma unroll
   for (int c = 0; c < NDOF; ++c) {
     int piv = c;

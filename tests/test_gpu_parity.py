@@ -1020,7 +1020,9 @@ def test_lm_step_in_the_reference_arithmetic_carries_the_reference_noise():
     assert float(cond.min()) >= 1e3
     assert q(out["f32"][0])[0] <= 1.5 * q(o32)[0] and q(out["f32"][0])[1] <= 1.5 * q(o32)[1]     # as close to truth as the reference's arithmetic
     assert q(out["f32"][1])[1] <= 2.5 * q(o32)[1]                                               # and to the reference itself, to that noise
-    assert float(out["f32"][0].max()) <= 16.0 and float(o32.max()) <= 16.0                       # nobody exceeds the noise model by an order
+    # no pose far outside the noise model - the poses next to a singularity (two small eigenvalues) included: with fused multiply-adds in the LU
+    # elimination the kernel's worst pose sat at 9.5 units against the oracle's 1.5 (r06; solve_lu_pivot is compiled without contraction since)
+    assert float(out["f32"][0].max()) <= 4.0 and float(o32.max()) <= 4.0
     assert q(out["f64"][0])[2] <= 0.05                                                          # fp64 inside: two orders below it
 
 
