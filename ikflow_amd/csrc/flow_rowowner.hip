@@ -320,10 +320,15 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_rowowner(RoArgs a) {
 // first share's groups are the member's own).  (G = 64 was measured and dropped: 0.336 ms at 64 rows against 0.286 with G = 32 on half
 // the chip - its partial-sum exchange reads 63 peers per thread.)
 // ---------------------------------------------------------------------------------------------------------------
-// How long a member waits for a peer before it gives the launch up: 5 ms of the constant 100 MHz clock (wall_clock64), checked every 16th
-// poll.  A resident peer answers within one subnet (< 50 us at any G); a peer that is NOT resident (another process holds its CU) costs the
-// call this wait plus the repair launch instead of the ~0.1 s a poll count of 2^18 took (r05).
-constexpr unsigned long long kClusterWaitTicks = 500000ull;
+// How long a member waits for a peer before it gives the launch up: about 5 ms, as a number of failed polls per kind of wait (a poll = s_sleep 1 +
+// one round of L2-missing loads; measured with a workgroup left out, tools/cluster_wait_probe.py: re-read passes of a tagged h2 gather, polls of
+// the tagged partial sums, polls of an epoch word).  A peer that IS resident answers within one subnet (< 50 us at any G: a handful of polls); one
+// that is not (another process holds its CU) costs the call this wait plus the repair launch - not the ~0.1 s of r05's 2^16 / 2^18 polls.
+// (Tried and dropped, same-box A/B with tools/lib_ab.py: the 100 MHz wall clock instead of counts - read in front of every wait + 4 % at 512 rows,
+// every 16th failed poll + 1.5 %, every 256th still + 2 % at 256 rows: not the reads, the registers they hold in kernels that have none to spare.)
+constexpr unsigned kGatherWaitPasses = 1u << 13;
+constexpr unsigned kSumWaitPolls = 1u << 14;
+constexpr unsigned kEpochWaitPolls = 1u << 14;
 
 __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; }   // HW_REG_XCC_ID
 
@@ -334,8 +339,13 @@ __device__ __forceinline__ unsigned ro_xcc_id() { return __builtin_amdgcn_s_getr
 // stays spread (0.34 against 0.28 ms at 128 rows) and G = 2 gains nothing.  NOTHING is assumed: a census at load (cluster_placement_census),
 // and in every launch a member publishes its XCC_ID in the top byte of every epoch word; a consumer that meets another XCD's id gives up
 // (abort word, host word = 2) BEFORE it reads a payload, the repair launch recomputes the rows, and the handle goes back to the spread form.
-// (TAG form: no epoch words - the members' XCC_IDs go through one word per member, written at the start of every launch and checked once, in
-// front of the first payload read: placement_ok.)
+// (TAG form: no epoch words - every member writes (launch number, XCC_ID) into a word of its own at the start of every launch, one 128-byte line
+// per row tile, and nothing in the launch reads them.  A peer on another XCD keeps its plain payload stores in ITS L2: the consumer sees the old
+// parity, re-reads, and its wait runs out (code 1) - never a wrong value.  The HOST, when it folds a give-up of such a launch, reads the words
+// (ikf_api.hip cluster_fold_give_up): members of one row tile that started that launch on different XCDs make it a placement failure - the
+// handle goes back to the spread form - instead of "a peer was not resident" (pause).  The kernel has no register to spare for this: the same
+// classification inside the failure path made the G = 4 / 8 kernels spill (+ 21 % at 512 rows), and checking the words up front, in front of
+// the first payload read, cost 2.3 % (same-box A/B, tools/lib_ab.py) - for a case the census at load has never let happen.)
 // TAG (r05): the hand-over without a drain, an epoch word or a poll of one - every exchanged float carries the subnet's parity in the LEAST
 // significant bit of its mantissa (<= 1 ulp; every member works with the same tagged values, so the forms still agree member for member).
 // The producer stores and goes on; a consumer reads the payload itself and re-reads what still shows the other parity: stale data of the
@@ -395,8 +405,11 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
   if (t == 0) s_ok = 1;
   // (TAG + LOCAL) where this member sits, for its peers' placement check (agent-scope store: visible outside this XCD's L2)
   if constexpr (TAG && LOCAL) {
-    if (t == 0) __hip_atomic_store(c.xcc_words + (size_t)rt * G + j, (c.launch_seq << 8) | pub_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) __hip_atomic_store(c.xcc_words + (size_t)rt * 32 + j, (c.launch_seq << 8) | pub_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // (tests, variant 191) workgroup 0 also BEHAVES like a member on another XCD - its payload never reaches its peers: it stops here (its rows
+  // are recomputed with its tile's by the repair launch)
+  if (TAG && LOCAL && c.test_far != 0 && blockIdx.x == 0) return;
   const int m0 = rt * RO_ROWS;
   const int lrow = lane & 15, lq = lane >> 4;
 #define RC_STAMP(i) if (a.trace != nullptr && t == 0) a.trace[(size_t)blockIdx.x * 64 + (i)] = __builtin_readcyclecounter();
@@ -528,11 +541,10 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       unsigned ok = 1, far = 0, late = 0;
       if (lane < G && lane != j) {
         unsigned n = 0, w;
-        const unsigned long long t_wait0 = wall_clock64();
         while (((w = __hip_atomic_load(flags + lane * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < e) {
           __builtin_amdgcn_s_sleep(1);
-          if ((++n & 15u) == 0) {
-            if (wall_clock64() - t_wait0 > kClusterWaitTicks) late = 1;
+          if ((++n & 63u) == 0) {
+            if (n > kEpochWaitPolls) late = 1;
             if (late || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
               ok = 0;
               break;
@@ -549,42 +561,6 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
           __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           // the host word is written by whoever FOUND the reason (plain stores to host memory: no PCIe atomics needed); a workgroup that
           // merely saw the abort word leaves it alone.  2: placement (the XCD-local form), 1: a peer never arrived
-          if (far) __hip_atomic_store(c.give_up, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          else if (late) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        s_ok = ok;
-      }
-    }
-    ro_barrier();
-    return s_ok != 0;
-  };
-  // (TAG + LOCAL) once per launch, before the first payload is read: every peer has started THIS launch (its word carries launch_seq) and
-  // sits on this member's XCD.  The tagged payload itself cannot tell: a peer on another XCD keeps its plain stores in ITS L2, and the
-  // consumer would merely time out.  false = gave up (code 2: placement; code 1: a peer never started)
-  auto placement_ok = [&]() -> bool {
-    if (wave == 0) {
-      unsigned ok = 1, far = 0, late = 0;
-      if (lane < G && lane != j) {
-        unsigned n = 0, w;
-        const unsigned long long t_wait0 = wall_clock64();
-        while (((w = __hip_atomic_load(c.xcc_words + (size_t)rt * G + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 8) != c.launch_seq) {
-          __builtin_amdgcn_s_sleep(1);
-          if ((++n & 15u) == 0) {
-            if (wall_clock64() - t_wait0 > kClusterWaitTicks) late = 1;
-            if (late || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-              ok = 0;
-              break;
-            }
-          }
-        }
-        if (ok && (w & 0xffu) != my_xcc) far = 1;
-      }
-      far = __any(far != 0) ? 1u : 0u;
-      late = __any(late != 0) ? 1u : 0u;
-      ok = (__all(ok != 0) && !far) ? 1u : 0u;
-      if (lane == 0) {
-        if (!ok) {
-          __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (far) __hip_atomic_store(c.give_up, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           else if (late) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -614,8 +590,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     const unsigned voffx = (unsigned)((row_t * RO_W + c4 * 4) * 4);
     float* const tdst = tile + row_t * RO_LDA + c4 * 4 + hw * (NLD * CS);
     ro_f4 v[NLD];
-    unsigned tries = 0, ok = 1, late = 0;
-    unsigned long long t_wait0 = 0;
+    unsigned tries = 0, ok = 1;
     for (;;) {
       unsigned bad = 0;
 #pragma unroll
@@ -629,19 +604,15 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       for (int r = 0; r < NLD; ++r)
         if (1 + r / RPP + hw * NLD < G) bad |= ro_tag_bad(v[r], par);
       if (!__any(bad != 0)) break;
-      if (tries == 0) t_wait0 = wall_clock64();
-      if ((++tries & 15u) == 0) {
-        late = (wall_clock64() - t_wait0 > kClusterWaitTicks) ? 1u : 0u;
-        if (late || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          ok = 0;
-          break;
-        }
+      if ((++tries & 15u) == 0 && (tries > kGatherWaitPasses || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        ok = 0;
+        break;
       }
       __builtin_amdgcn_s_sleep(1);
     }
     if (!ok && lane == 0) {
       __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (late) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tries > kGatherWaitPasses) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       s_ok = 0;
     }
 #pragma unroll
@@ -787,9 +758,6 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     else RC_PUBLISH(2 * e0 + 1)
     RC_PHASE(2)
     // ---- hidden 3: tile1 (h2) -> own columns of tile0 (h3 stays here)
-    if constexpr (TAG && LOCAL) {
-      if (s == 0 && !placement_ok()) return;   // (once per launch, in front of the first payload read)
-    }
     RC_LAYER(2 * s + 1, b3, tile1, rsX1, 2 * e0 + 1, true)
     RC_EPILOGUE(tile0, false, rsX1)
     ro_barrier();
@@ -828,8 +796,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
           const int row = t >> 4, o = t & 15;
           constexpr int CH = G < 16 ? G : 16;   // loads in flight together
           float sum = sm[o];   // b_last (zero beyond n_out)
-          unsigned tries = 0, ok = 1, late = 0;
-          unsigned long long t_wait0 = 0;
+          unsigned tries = 0, ok = 1;
 #pragma unroll
           for (int mb = 0; mb < G; mb += CH) {
             float part[CH];
@@ -840,13 +807,9 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
 #pragma unroll
               for (int q = 0; q < CH; ++q) bad |= (mb + q == j) ? 0u : ((__float_as_uint(part[q]) ^ tag_par) & 1u);
               if (!__any(bad != 0) || !ok) break;
-              if (tries == 0) t_wait0 = wall_clock64();
-              if ((++tries & 15u) == 0) {
-                late = (wall_clock64() - t_wait0 > kClusterWaitTicks) ? 1u : 0u;
-                if (late || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                  ok = 0;
-                  break;
-                }
+              if ((++tries & 15u) == 0 && (tries > kSumWaitPolls || __hip_atomic_load(c.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                ok = 0;
+                break;
               }
               __builtin_amdgcn_s_sleep(1);
             }
@@ -855,7 +818,7 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
           }
           if (!ok && lane == 0) {
             __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (late) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tries > kSumWaitPolls) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             s_ok = 0;
           }
           s_sum[row * RO_RS + o] = sum;

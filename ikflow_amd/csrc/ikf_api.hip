@@ -139,6 +139,8 @@ struct ikf_model {
   int cl_census_ok = -1;          // the placement census at load: workgroups b and b + 8 k share an XCD (1) or not (0); -1 not asked
   int cl_far_next = 0;            // tests (ikf_set_gemm_variant 191): the next XCD-local launch's workgroup 0 publishes a wrong XCC_ID
   unsigned cl_launch_seq = 0;     // tagged + XCD-local launches carry a 24-bit sequence number in their placement words (RcArgs::launch_seq)
+  int cl_tl_nrt = 0, cl_tl_G = 0; // row tiles / members of the most recent tagged + XCD-local launch (whose placement words a give-up makes the host read)
+  unsigned* cl_tl_words = nullptr;
   int cl_local = 1;               // G = 4 / 8 / 16: the form with a row tile's members on one XCD (hand-over through its L2); 0 after a member met a
                                   // peer on another XCD (placement is verified in the launch, never assumed) or by ikf_set_gemm_variant 189
 
@@ -1228,14 +1230,47 @@ static bool rowowner_allowed(const ikf_model* m) {
   return m->ro_stream != nullptr && m->ro_mode != 0 && m->precision == 0 && m->loaded &&
          (m->ro_mode == 1 || (m->gemm_variant < 0 && m->tile_cfg < 0 && m->fuse_tail == 0));
 }
+// A wait of a tagged + XCD-local launch ran out: was it placement?  Every member of that launch wrote (launch number << 8 | XCC_ID) into its word
+// at its start (flow_rowowner.hip); launches queued behind the one that gave up returned before they wrote anything, so the largest launch number
+// found is the failed launch's.  Members of one row tile that ran it on different XCDs = the XCD-local form was used where it must not be.
+// Rare path (a 5 ms stall has just happened): one device synchronisation and a copy of a few KB.
+static bool cluster_tagged_local_misplaced(ikf_model* m) {
+  DeviceGuard guard(m->device);
+  if (guard.err != hipSuccess || m->cl_tl_words == nullptr) return false;
+  const int n_rt = m->cl_tl_nrt, G = m->cl_tl_G;
+  std::vector<unsigned> w((size_t)n_rt * 32, 0xffffffffu);
+  if (hipDeviceSynchronize() != hipSuccess) return false;
+  if (hipMemcpy(w.data(), m->cl_tl_words, w.size() * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return false;
+  unsigned seq = 0;
+  bool any = false;
+  for (int rt = 0; rt < n_rt; ++rt)
+    for (int j = 0; j < G; ++j) {
+      const unsigned v = w[(size_t)rt * 32 + j];
+      if (v == 0xffffffffu) continue;
+      if (!any || (((v >> 8) - seq) & 0xffffffu) < 0x800000u) seq = v >> 8;   // (24-bit sequence numbers wrap)
+      any = true;
+    }
+  if (!any) return false;
+  for (int rt = 0; rt < n_rt; ++rt) {
+    int first = -1;
+    for (int j = 0; j < G; ++j) {
+      const unsigned v = w[(size_t)rt * 32 + j];
+      if (v == 0xffffffffu || (v >> 8) != seq) continue;
+      if (first < 0) first = (int)(v & 0xffu);
+      else if ((int)(v & 0xffu) != first) return true;
+    }
+  }
+  return false;
+}
 static const long long kClusterFirstPause = 16, kClusterMaxPause = 65536;
 static const int kClusterCleanStreak = 64;
 // folds a pending give-up word into the handle's state (no side effect otherwise)
 static void cluster_fold_give_up(ikf_model* m) {
   if (!m->h_cl_give_up || *m->h_cl_give_up == 0) return;
   // an earlier call's cluster launch gave up (its rows were recomputed by the repair launch)
-  const int why = *m->h_cl_give_up;
+  int why = *m->h_cl_give_up;
   *m->h_cl_give_up = 0;
+  if (why == 1 && m->cl_local != 0 && m->cl_tl_nrt > 0 && cluster_tagged_local_misplaced(m)) why = 2;
   ++m->cl_repairs;
   m->cl_clean = 0;
   m->cl_tag_dirty = true;                        // (whichever hand-over it was: the tagged buffers are re-created before their next use)
@@ -1437,6 +1472,7 @@ static ikf_status run_flow_cluster(ikf_model* m, int G, const PoseSource& ps, co
     m->cl_launch_seq = (m->cl_launch_seq + 1) & 0xffffffu;
     if (m->cl_launch_seq == 0xffffffu) m->cl_launch_seq = 0;
     c.launch_seq = m->cl_launch_seq;
+    if (local) { m->cl_tl_nrt = c.n_rt; m->cl_tl_G = G; m->cl_tl_words = c.xcc_words; }
     IKF_HIP(prof_mark(m, s));
     IKF_HIP(launch_flow_cluster_tagged(c, G, s, m->cl_drop_next, local));
   } else {

@@ -238,9 +238,10 @@ struct RcArgs {            // cluster form (k_flow_cluster<G>): G workgroups per
   unsigned* flags;         // [n_rt][G][32] epoch published by each member (one 128-byte line each) = pbuf + n_rt * G * 256 (one memset)
   unsigned* abort_word;    // device word behind the flags (same memset): set when a wait ran out - every other wait ends, and the
                            // row-owner launch queued behind this one (run_if = abort_word) recomputes the chunk
-  int test_far;            // tests: workgroup 0 of the XCD-local form publishes a wrong XCC_ID (its peers must give up with code 2)
-  unsigned* xcc_words;     // tagged + XCD-local form: [n_rt][G] words (launch_seq << 8 | XCC_ID), one per member, written at the start of every
-                           // launch; a member compares its peers' ids with its own BEFORE it reads a payload (a word outside the partial sums)
+  int test_far;            // tests: workgroup 0 of the XCD-local form publishes a wrong XCC_ID (its peers must give up with code 2); in the tagged
+                           // form it also drops its payload stores, as a member whose stores stay in another XCD's L2 would
+  unsigned* xcc_words;     // tagged + XCD-local form: [n_rt][32] words (launch_seq << 8 | XCC_ID), one per member, one 128-byte line per row tile,
+                           // written at the start of every launch; read only when a wait has run out (was it placement, or a peer not resident?)
   unsigned launch_seq;     // ... 24 bits, never 0xffffff (what the buffers are created as), another value in every launch
   int* give_up;            // host-visible twin: 1 = a wait ran out (the engine stops using the cluster form on this handle), 2 = a member
                            // of the XCD-local form met a peer on another XCD (the engine goes back to the spread form)

@@ -1937,12 +1937,13 @@ def test_cluster_form_xcd_local_placement_check_falls_back_to_the_spread_form():
     assert torch.equal(s.generate_ik_solutions(P, latent=L), good) and eng.cluster_repairs == 1
 
 
-def test_cluster_form_tagged_xcd_local_placement_check_in_every_launch():
-    """The DEFAULT hand-over (tagged payload) in its XCD-local form assumes nothing about placement either (r06): it has no epoch words, so every
-    member writes (launch number, XCC_ID) into a word of its own at the start of every launch, and once per launch - in front of the first
-    payload read - a member compares its peers' ids with its own.  Variant 191 makes workgroup 0 claim another XCD: its peers give up with the
-    placement code, the repair launch recomputes the rows, the handle goes on with the SPREAD form (not without the cluster form, and without
-    a pause), same bits as before."""
+def test_cluster_form_tagged_xcd_local_placement_is_classified_when_a_wait_runs_out():
+    """The DEFAULT hand-over (tagged payload) in its XCD-local form assumes nothing about placement either (r06).  It has no epoch words; a member on
+    another XCD would keep its plain payload stores in ITS L2, its peers would see the old parity, re-read, and run out of patience (2 - 4 ms) - never a
+    wrong value.  So every member writes (launch number, XCC_ID) into a word of its own at the start of every launch, and the HOST, when it folds the
+    give-up, reads the words of that launch: members of one row tile that ran it on different XCDs make it a placement failure (the handle goes on with
+    the SPREAD form, without a pause) instead of "a peer is not resident" (pause).  Variant 191 makes workgroup 0 such a member - wrong id, payload stores dropped: the
+    repair launch recomputes the rows, and the spread form gives the same bits as before."""
     robot, hp, lay, sd = panda_model()
     s = _solver(robot, hp, sd)
     eng = s.engine(DEV)

@@ -35,7 +35,7 @@ def test_results_are_a_function_of_the_inputs_next_to_a_co_tenant(case, tmp_path
 
 def test_cluster_form_soak_random_sizes_with_injected_give_ups():
     """400 calls of random sizes 129 .. 3300 queued without synchronisation through the default (tagged) cluster hand-over, a give-up injected
-    every 50th call (a workgroup short: waits run out after 5 ms, repair launch, pause, buffers re-created): every result within 1e-5 of the
+    every 50th call (a workgroup short: waits run out after 2 - 4 ms, repair launch, pause, buffers re-created): every result within 1e-5 of the
     same rows through the row-owner launch."""
     r, lines = _run([os.path.join(ROOT, "tools", "cluster_soak.py"), "400", "50"])
     assert r.returncode == 0 and lines, (r.stdout[-1500:], r.stderr[-1500:])
