@@ -759,8 +759,20 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     RC_PHASE(2)
     // ---- hidden 3: tile1 (h2) -> own columns of tile0 (h3 stays here)
     RC_LAYER(2 * s + 1, b3, tile1, rsX1, 2 * e0 + 1, true)
-    RC_EPILOGUE(tile0, false, rsX1)
-    ro_barrier();
+    // h3 feeds nothing but this member's last Linear, and a wave that ran the whole k range of its blocks (KS == 1) holds exactly the last Linear's
+    // B operand of those blocks in its accumulators (row = lane % 16, four consecutive k): it stays in registers - no LDS round trip, no barrier
+    [[maybe_unused]] ro_f4 h3v[NCB];
+    if constexpr (KS == 1) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        ro_f4 v = acc[cb];
+        if constexpr (TWO) v += accb[cb];
+        h3v[cb] = __builtin_elementwise_max(v, v * a.slope);
+      }
+    } else {
+      RC_EPILOGUE(tile0, false, rsX1)
+      ro_barrier();
+    }
     RC_PHASE(3)
     // ---- last Linear over the member's own h3 columns: per-wave partial sums -> red[wave] -> the member's partial -> P[j], epoch 3 s + 3
     {
@@ -770,7 +782,9 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       if (ks == 0) {   // (k split: one wave per block of the member's h3 columns)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-          const ro_f4 hf = *reinterpret_cast<const ro_f4*>(tile0 + lrow * RO_LDA + (bw + cb) * 16 + 4 * lq);
+          ro_f4 hf;
+          if constexpr (KS == 1) hf = h3v[cb];
+          else hf = *reinterpret_cast<const ro_f4*>(tile0 + lrow * RO_LDA + (bw + cb) * 16 + 4 * lq);
 #pragma unroll
           for (int cc = 0; cc < 4; ++cc) p4[cc] = RO_MFMA(wl[cb][cc], hf[cc], p4[cc]);
         }
