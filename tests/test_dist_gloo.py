@@ -128,6 +128,8 @@ class _FakeSolver:
         return torch.tanh(y) + 0.5 * latent
 
     def generate_exact_ik_solutions(self, target_poses, **kw):
+        self.exact_calls = getattr(self, "exact_calls", 0) + 1
+        assert target_poses.shape[0] > 0, "the solver is never called on an empty shard"
         sol = torch.tanh(target_poses)
         valid = target_poses[:, 0] > 0
         return torch.where(valid[:, None], sol, torch.zeros_like(sol)), valid
@@ -186,15 +188,19 @@ def _worker_from_shard(rank, world, port, n, q):
         ok = ok and bool(torch.equal(local, torch.tanh(mine) + 0.5 * lat[rank]))
         # no two ranks draw the same block, and a rank's block does not depend on the world size
         ok = ok and all(not torch.equal(lat[0][: min(rows)], lat[r][: min(rows)]) for r in range(1, world) if min(rows) > 0)
-        if all(r > 0 for r in rows):
-            sol, valid = sharded_generate_exact_ik_solutions_from_shard(s, mine)
-            ws, wv = s.generate_exact_ik_solutions(torch.cat(blocks, dim=0))
-            ok = ok and bool(torch.equal(sol, ws)) and bool(torch.equal(valid, wv)) and valid.dtype == torch.bool
+        # exact: also when a rank has no rows at all (r06: it still enters the collective, with empty solutions / flags)
+        calls_before = getattr(s, "exact_calls", 0)
+        sol, valid = sharded_generate_exact_ik_solutions_from_shard(s, mine)
+        ws, wv = s.generate_exact_ik_solutions(torch.cat(blocks, dim=0))
+        ok = ok and bool(torch.equal(sol, ws)) and bool(torch.equal(valid, wv)) and valid.dtype == torch.bool and sol.shape == (sum(rows), 7)
+        if rows[rank] == 0:
+            ok = ok and getattr(s, "exact_calls", 0) == calls_before + 1   # (only the expectation above called the solver: the empty shard did not)
         ok = ok and bool(torch.equal(gather_blocks(mine), torch.cat(blocks, dim=0)))
         # the stepper: equal shards, the gather double buffered
         B = 5
         shard = torch.randn(B, 7, generator=torch.Generator().manual_seed(rank))
         st = ShardedStepper(lambda: torch.tanh(shard), world, rank, B, 7, "cpu", True)
+        ok = ok and st.last_gathered() is None   # (nothing gathered before the first step)
         for _ in range(3):
             sol = st.step()
         st.fence()
