@@ -17,7 +17,7 @@ LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libikflow_amd.so")
 PROBES_LIB_PATH = os.path.join(LIB_DIR, "libikflow_amd_probes.so")
 SOURCES = ["flow_kernels.hip", "flow_fused.hip", "flow_rowowner.hip", "flow_split.hip", "kin_kernels.hip", "ikf_api.hip"]
-HEADERS = [os.path.join(CSRC, "ikf_internal.h"), os.path.join(CSRC, "flow_split_dma.inc"), os.path.join(CSRC, "flow_fused_probes.inc"), os.path.join(_HERE, "..", "include", "ikflow_amd.h"),
+HEADERS = [os.path.join(CSRC, "ikf_internal.h"), os.path.join(CSRC, "kin_math.h"), os.path.join(CSRC, "flow_split_dma.inc"), os.path.join(CSRC, "flow_fused_probes.inc"), os.path.join(_HERE, "..", "include", "ikflow_amd.h"),
            os.path.join(_HERE, "..", "include", "ikflow_amd_debug.h")]
 ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -5,6 +5,7 @@
 
 #include "../../include/ikflow_amd.h"
 #include "../../include/ikflow_amd_debug.h"
+#include "kin_math.h"
 
 namespace ikf {
 
@@ -315,14 +316,7 @@ hipError_t launch_wfrag_pack(const float* W, int N, int K, float* out, hipStream
 hipError_t launch_split32_pack(const float* d_src, long long rows, int K, void* d_dst, int* d_flag, hipStream_t s);
 const char* split_kernel_name();
 
-// kin_kernels.hip
-struct Chain {
-  int ndof;
-  ikf_joint joints[IKF_MAX_DOF];
-  float tool[12];
-  float lo[IKF_MAX_DOF];
-  float hi[IKF_MAX_DOF];
-};
+// kin_kernels.hip (struct Chain and the per-row arithmetic: kin_math.h)
 // IKF_MAX_CAPSULES (24) comes from include/ikflow_amd.h
 constexpr int IKF_MAX_CAPSULE_PAIRS = IKF_MAX_CAPSULES * (IKF_MAX_CAPSULES - 1) / 2;
 struct CollisionModel {
