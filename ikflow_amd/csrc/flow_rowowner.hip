@@ -610,6 +610,9 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
       }
       __builtin_amdgcn_s_sleep(1);
     }
+#ifdef IKF_RC_FINE_STAMPS
+    if (a.trace != nullptr && t == 0) a.trace[(size_t)blockIdx.x * 64 + 50] += tries;   // failed passes, summed over the call's gathers
+#endif
     if (!ok && lane == 0) {
       __hip_atomic_store(c.abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (tries > kGatherWaitPasses) __hip_atomic_store(c.give_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -700,7 +703,9 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     _Pragma("unroll") for (int i_ = 0; i_ < KGW; ++i_) {                                                                 \
       if (WAIT && i_ == WAIT_AT) {                                                                                       \
         if constexpr (TAG) {                                                                                             \
+          RC_FINE(46)                                                                                                    \
           if (!gather_tagged(rsXin, tile_in, tag_par)) return;                                                           \
+          RC_FINE(47)                                                                                                    \
         } else {                                                                                                         \
           if (!wait_peers(e_in)) return;                                                                                 \
           gather(rsXin, tile_in);                                                                                        \
@@ -727,6 +732,11 @@ __global__ __launch_bounds__(RO_WAVES * 64) void k_flow_cluster(RcArgs c) {
     const unsigned tag_par = (unsigned)s & 1u;   // (TAG) parity carried by everything this subnet exchanges
     RC_STAMP(1 + (s < 31 ? s : 31))
 #define RC_PHASE(i) if (s == 2) { RC_STAMP(40 + (i)) }
+#ifdef IKF_RC_FINE_STAMPS   /* probes: the h2 gather of subnet 2 on its own (tools/rowowner_probe.hip) */
+#define RC_FINE(i) if (s == 2) { RC_STAMP(i) }
+#else
+#define RC_FINE(i)
+#endif
     RC_PHASE(0)
     small_load(s, 1, b2);
     small_load(s, 2 + RO_KG, b3);

@@ -121,6 +121,9 @@ int main(int argc, char** argv) {
     rc.give_up = h_give_up;
     if (duo == 4 || duo == 5)   // the tagged hand-over: buffers created as 0xff bytes, nothing zeroed per launch
       CK(cluster_tagged_init(rc.xbuf, cluster_xbuf_floats(n_rt2), rc.pbuf, cluster_sync_bytes(n_rt2, G) - 128, rc.abort_word, nullptr));
+    CK(hipMalloc(&rc.xcc_words, (size_t)(n_rt2 + 8) * 32 * 4));   // (r06: the tagged XCD-local form's placement words, one line per row tile)
+    CK(hipMemset(rc.xcc_words, 0xff, (size_t)(n_rt2 + 8) * 32 * 4));
+    rc.launch_seq = 1;
   }
   auto launch = [&]() -> hipError_t {
     if (G > 1) { rc.ro = a; if (duo == 4 || duo == 5) return launch_flow_cluster_tagged(rc, G, nullptr, 0, /*local=*/duo == 4); return duo == 3 ? launch_flow_pair(rc, G, nullptr) : duo == 1 ? launch_flow_duo(rc, G, nullptr) : launch_flow_cluster(rc, G, nullptr, 0, /*local=*/duo == 2); }
@@ -247,6 +250,18 @@ int main(int argc, char** argv) {
       printf("  XCD %d: %d workgroups, mean %.1f us, %.3f GHz, mean start +%.1f us, mean end +%.1f us\n", x, n, us / n, cyc / us * 1e-3, st / n, en / n);
     }
   }
+#ifdef IKF_RC_FINE_STAMPS
+  if (n_sub > 2 && (duo == 4 || duo == 5)) {   // the tagged h2 gather of subnet 2 taken apart: own-slice k groups, the wait for the peers, the rest of hidden 3
+    std::vector<double> own, wait, rest, tries;
+    for (unsigned g = 0; g < grid; ++g) {
+      const unsigned long long* p = &tr[(size_t)g * 64];
+      if (p[46] == 0 || p[47] == 0) continue;
+      own.push_back((double)(p[46] - p[42])); wait.push_back((double)(p[47] - p[46])); rest.push_back((double)(p[43] - p[47])); tries.push_back((double)p[50] / (3.0 * n_sub));
+    }
+    printf("  hidden 3 of subnet 2: own-slice k groups median %.0f max %.0f | h2 gather (issue -> all peers in LDS) median %.0f min %.0f max %.0f | remaining k groups + epilogue median %.0f | failed passes per gather median %.2f max %.2f\n",
+           med(own), mx(own), med(wait), mn(wait), mx(wait), med(rest), med(tries), mx(tries));
+  }
+#endif
   if (n_sub > 2 && duo == 3) {   // pair form: the four slots of subnet 2 (compute wave 0) and the comm team's four jobs (comm wave 0)
     const char* cn[4] = {"A.h2", "B.h2", "A.h3 + last", "B.h3 + last"};
     for (int k = 0; k < 4; ++k) {
