@@ -1967,6 +1967,37 @@ def test_cluster_form_tagged_xcd_local_placement_is_classified_when_a_wait_runs_
     assert torch.equal(again, good[0]) and eng.cluster_repairs == 1   # spread placement: the same tagged values through another memory path
 
 
+@pytest.mark.parametrize("n", [512, 4096, 5000])
+def test_approximate_call_can_be_captured_into_a_hip_graph(n):
+    """After ikf_load_weights + ikf_reserve an approximate call allocates nothing and never synchronises (include/ikflow_amd.h), so it can be
+    captured into a HIP graph (torch.cuda.CUDAGraph) - cluster form, row-owner launch and a two-chunk plan - and the replay writes the call's bits."""
+    robot, hp, lay, sd = panda_model()
+    s = _solver(robot, hp, sd)
+    eng = s.engine(DEV)
+    eng.reserve(8192)
+    _, poses = reachable_poses(robot, n, 171)
+    lat = latents(n, lay.dim, 172)
+    P, L = poses.to(DEV), lat.to(DEV)
+    ref = s.generate_ik_solutions(P, latent=L).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            s.generate_ik_solutions(P, latent=L)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = s.generate_ik_solutions(P, latent=L)
+    for _ in range(3):
+        with torch.inference_mode():
+            out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    assert eng.cluster_repairs == 0
+    assert torch.equal(s.generate_ik_solutions(P, latent=L), ref)   # (and the handle is as usable as before)
+
+
 def test_plan_of_a_call_by_batch_size():
     """plan_flow's decisions at representative sizes (released Panda shape, 256 CUs): what DESIGN.md section 4.0 tabulates.  Other shapes
     (TINY: width 256) and the f16x3 mode stay on the per-layer kernels whatever the size."""
