@@ -68,7 +68,7 @@ ikf_status ikf_plan_describe_for(int n_cu, int64_t rows, int rowowner_allowed, i
  *                    exchange activations inside the launch): never / by the cost model (default) / whenever its grid fits; 188: tests -
  *                    the next cluster launch runs one workgroup short (exercises the repair launch)
  *   189 / 190        cluster form with 4 / 8 / 16 members: a row tile's members spread over the XCDs / all on one XCD, hand-over through that
- *                    XCD's L2 (default; the placement is verified inside the launch and the handle falls back to 189 by itself);
+ *                    XCD's L2 (default; every launch publishes its members' XCC_IDs and the handle falls back to 189 by itself on a mismatch);
  *                    191: tests - the next such launch's workgroup 0 publishes a wrong XCC_ID (exercises that fall-back)
  *   192 / 193        cluster form with 2 .. 16 members: hand-over by a drain + an epoch word per member / by payload whose every float carries the
  *                    subnet's parity in its last mantissa bit (default: no drain, no epoch words, no memset in front of the launch)
