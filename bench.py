@@ -812,7 +812,9 @@ def main():
     if live["avg_us"] is not None:
         prof_us, prof_src = live["avg_us"], "rocprofv3 --kernel-trace --stats in this run"
     # launch by launch: the steady-state mean (the clock ramp behind the trace's idle gaps left out) is what `roofline.frac` is computed from
-    trace, trace_src = (live.get("trace"), "rocprofv3 --kernel-trace in this run") if live.get("trace") else (rocprof_kernel_steady(ksub) if headline_cfg else (None, None))
+    # (only a trace of THIS run sets `frac`; without one - N > 1, --no-live-pmc - `frac` is the hipEvent figure and the committed trace summary rides along)
+    trace, trace_src = (live.get("trace"), "rocprofv3 --kernel-trace in this run") if live.get("trace") else (None, None)
+    committed_trace, committed_trace_src = rocprof_kernel_steady(ksub) if headline_cfg else (None, None)
     steady_us = trace.get("steady_mean_us") if trace else None
     frac_event = achieved / FP32_MFMA_PEAK_TFLOPS
     frac_steady = (flop_per_launch / (steady_us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS) if steady_us else None
@@ -898,6 +900,7 @@ def main():
                      "frac": frac_steady if frac_steady else frac_event, "frac_source": (f"steady-state mean of {trace_src}" if frac_steady else "hipEvent pairs (no kernel trace available)"),
                      "frac_event": frac_event, "achieved_event": achieved,
                      "kernel_trace": trace, "kernel_trace_source": trace_src,
+                     "kernel_trace_committed": committed_trace, "kernel_trace_committed_source": committed_trace_src,
                      "traffic": live_traffic if live_traffic is not None else traffic,
                      "traffic_unit": "HBM bytes per launch",
                      "traffic_source": live_note if live_traffic is not None else traffic_src,
