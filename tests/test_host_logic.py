@@ -398,3 +398,36 @@ def test_planner_decisions_and_invariants_host_side():
             assert sum(int(r) for _, r in chunks) == rows and all(f.startswith("cluster") for f, _ in chunks)
             assert all((int(r) + 15) // 16 * int(f[len("cluster"):]) <= n_cu for f, r in chunks)
             assert dt < 0.5, dt
+
+
+def test_kernel_trace_steady_state_summary(tmp_path):
+    """tools/kernel_trace_steady.py (what bench.py's roofline.frac is computed from): raw mean, median and the steady-state mean - a launch counts
+    once 10 launches of the kernel have run since the queue's last idle gap (> 200 us): the clock-ramp launches behind a gap stay out."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_trace_steady import kernel_trace_stats
+
+    rows, t = [], 1_000_000
+    def launch(name, dur_ns, gap_ns=2_000):
+        nonlocal t
+        t += gap_ns
+        rows.append((name, t, t + dur_ns))
+        t += dur_ns
+    launch("void ikf::k_rowowner_pack(ikf::RoPackArgs)", 10_000)
+    for i in range(30):                       # behind the start of the trace: 10 ramp launches (slow), then steady ones
+        launch("void ikf::k_flow_rowowner<4>(ikf::RoArgs)", 3_500_000 if i < 10 else 2_800_000)
+    launch("void ikf::k_flow_rowowner<4>(ikf::RoArgs)", 3_400_000, gap_ns=50_000_000)   # an idle gap: the ramp starts over
+    for i in range(19):
+        launch("void ikf::k_flow_rowowner<4>(ikf::RoArgs)", 3_000_000 if i < 9 else 2_800_000)
+    launch("void ikf::k_flow_gemm_skinny<true, 2>(ikf::FusedGemmArgs)", 1_000)            # ("skinny" kernels are never the dominant one)
+    p = tmp_path / "kt_kernel_trace.csv"
+    with open(p, "w") as f:
+        f.write('"Kind","Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+        for name, a, b in rows:
+            f.write(f'"KERNEL_DISPATCH","{name}",{a},{b}\n')
+    s = kernel_trace_stats(str(p), "k_flow_rowowner")
+    assert s["launches"] == 50 and s["steady_launches"] == 30
+    assert abs(s["steady_mean_us"] - 2800.0) < 1e-6 and abs(s["median_us"] - 2800.0) < 1e-6
+    assert s["mean_us"] > 2950.0 and s["max_us"] == 3500.0
+    assert kernel_trace_stats(str(p), "k_split_gemm") is None
